@@ -1,0 +1,100 @@
+/* marl_hip.h - C ABI of libmarl_hip.so: the MI355X (gfx950) implementation of the reference's hot
+ * path - the five-field L'Heureux (2018) RHS and its explicit Runge-Kutta time loops.
+ *
+ * Every entry point names the reference interface it stands in for (paths relative to the
+ * reference repository).  Plain pointers and sizes only; no C++ or torch types cross this ABI.
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - all floating point data is float64; a state vector is float64[5*N] FIELD-MAJOR
+ *     (CA | CC | cCa | cCO3 | Phi, each N contiguous: marlpde/Evolve_scenario.py:64-65,76-86) unless a
+ *     `layout` argument says MARL_LAYOUT_TILED (device buffers only);
+ *   - functions return 0 on success, <0 on error (invalid argument / HIP failure; text from
+ *     marl_last_error), and the solver status where documented;
+ *   - `*_dev` variants take DEVICE pointers (e.g. torch.Tensor.data_ptr()), enqueue on the context's
+ *     stream and do not synchronise unless documented; the others take HOST pointers, copy in/out
+ *     and return after the stream is idle;
+ *   - a context is not thread safe (the reference's RHS object is stateful too:
+ *     marlpde/LHeureux_model.py:90,168-172); use one context per thread/GPU/stream;
+ *   - NaN/Inf in a state are data, not errors (the reference's numba path behaves the same way).
+ */
+#ifndef MARL_HIP_H
+#define MARL_HIP_H
+
+#include "marl_params.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct marl_ctx marl_ctx;
+
+#define MARL_LAYOUT_FIELD_MAJOR 0 /* y[f*N + i]                                   (reference layout) */
+#define MARL_LAYOUT_TILED 1       /* y[(i>>6)*320 + f*64 + (i&63)], ceil(N/64)*320 doubles            */
+
+/* ---- model construction ---------------------------------------------------------------------
+ * Replaces LMAHeureuxPorosityDiff.__init__ (marlpde/LHeureux_model.py:12-133): derives the
+ * constants (:36-72, :130-133), the boundary rules (:26-30) and the depth mask
+ * (marlpde/Evolve_scenario.py:51-54), and uploads them.  `params` holds n_instances blocks
+ * (a parameter sweep: one block per instance; the reference runs one instance per process).
+ * All instances share N. */
+int marl_ctx_create(const marl_params* params, int64_t n_instances, int64_t N, int device, marl_ctx** out);
+
+void marl_ctx_destroy(marl_ctx* ctx);
+const char* marl_last_error(const marl_ctx* ctx); /* ctx may be NULL: error of the last failed create */
+int marl_set_stream(marl_ctx* ctx, void* hip_stream); /* NULL = the context's own stream */
+int marl_synchronize(marl_ctx* ctx);
+/* Tuning knobs (kernel variant selection); unknown names are an error.  See DESIGN.md. */
+int marl_set_option(marl_ctx* ctx, const char* name, int64_t value);
+/* Derived constants of instance `inst` in the order of tests/golden/derived_constants.json:
+ * delta_x nu1 nu2 KRat dCa dCO3 delta Da lambda_ auxcon rhorat0 rhorat presum F_fixed dPhi_fixed
+ * Peclet_min Peclet_max, then mask_lo, mask_hi (as doubles). */
+int marl_get_constants(const marl_ctx* ctx, int64_t inst, double out[19]);
+/* doubles needed for one instance's state in `layout` */
+int64_t marl_state_doubles(const marl_ctx* ctx, int layout);
+
+/* ---- RHS ---------------------------------------------------------------------------------------
+ * Replaces the solve_ivp callable  fun(t, y, progress_proxy, progress_dt, t0) / fun_numba(...)
+ * (marlpde/LHeureux_model.py:162-288, :290-359 -> pde_rhs :361-522).  `t` is accepted and ignored
+ * (the system is autonomous; the reference only uses t for its progress bar).  y and dydt must not
+ * alias.  For n_instances > 1 the buffers hold the instances one after another. */
+int marl_rhs(marl_ctx* ctx, double t, const double* y, double* dydt);
+int marl_rhs_dev(marl_ctx* ctx, double t, const double* y_dev, double* dydt_dev, int layout);
+
+/* ---- monitors ----------------------------------------------------------------------------------
+ * Replaces the seven event functions zeros, zeros_CA, zeros_CC, ones_CA_plus_CC, ones_Phi,
+ * zeros_U, zeros_W (marlpde/LHeureux_model.py:524-593), in that order.  out: [n_instances][7] (host). */
+int marl_events(marl_ctx* ctx, const double* y, double* out);
+int marl_events_dev(marl_ctx* ctx, const double* y_dev, int layout, double* out); /* synchronises */
+
+int marl_convert_layout_dev(marl_ctx* ctx, const double* src_dev, double* dst_dev, int src_layout, int dst_layout);
+
+/* ---- fixed-step classical RK4 (BASELINE config 2; no counterpart in the reference, which only
+ * remarks that forward Euler fails: README.md:9).  y is advanced in place by nsteps steps of dt. */
+int marl_integrate_rk4(marl_ctx* ctx, double* y, double dt, int64_t nsteps);
+int marl_integrate_rk4_dev(marl_ctx* ctx, double* y_dev, int layout, double dt, int64_t nsteps);
+/* batched sweep: one dt per instance (host array, n_instances entries); FIELD-MAJOR device state */
+int marl_sweep_rk4_dev(marl_ctx* ctx, double* y_dev, const double* dt, int64_t nsteps);
+
+/* ---- adaptive Dormand-Prince RK45 ---------------------------------------------------------------
+ * Replaces  scipy.integrate.solve_ivp(fun, t_span, y0, method="RK45", first_step=, rtol=, atol=,
+ * t_eval=, events=[7 monitors])  as called at marlpde/Evolve_scenario.py:104-109 (controller:
+ * scipy/integrate/_ivp/rk.py:111-176; driver: ivp.py:654-723).  y: in y(t0), out y(stats->t).
+ * t_eval (may be NULL): sorted sample times within [t0, t1]; y_eval receives n_eval x 5N doubles,
+ * sample-major (dense output, rk.py:560-574).  t_events (may be NULL): 7 x max_events root times of the
+ * monitors' sign changes, located like scipy does (dense output + Brent, ivp.py:51-76); the counts are
+ * stats->n_events.  max_attempts = 0: unlimited.  Returns stats->status. */
+int marl_integrate_rk45(marl_ctx* ctx, double* y, double t0, double t1, double first_step, double rtol, double atol,
+                        const double* t_eval, int64_t n_eval, double* y_eval, double* t_events, int64_t max_events,
+                        int64_t max_attempts, marl_stats* stats);
+int marl_integrate_rk45_dev(marl_ctx* ctx, double* y_dev, int layout, double t0, double t1, double first_step,
+                            double rtol, double atol, int64_t max_attempts, marl_stats* stats); /* synchronises */
+/* batched sweep: per-instance controller; all instances share t0, t1, first_step, tolerances.
+ * stats: host array of n_instances entries.  FIELD-MAJOR device state.  Synchronises. */
+int marl_sweep_rk45_dev(marl_ctx* ctx, double* y_dev, double t0, double t1, double first_step, double rtol,
+                        double atol, int64_t max_attempts, marl_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MARL_HIP_H */

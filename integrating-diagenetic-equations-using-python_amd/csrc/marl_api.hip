@@ -1,0 +1,834 @@
+// marl_api.hip - host side of libmarl_hip.so: context management, constant derivation and kernel
+// launches behind the C ABI declared in include/marl_hip.h.  gfx950 only; no CPU fallback - every
+// entry point needs a HIP device and fails with an error text otherwise.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/marl_hip.h"
+#include "marl_kernels.h"
+
+using namespace marl;
+
+static_assert(MARL_NFIELDS == NF, "field count");
+static std::string g_create_error;
+
+struct marl_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr, own_stream = nullptr;
+    int64_t N = 0, batch = 0;
+    Slab slab{};
+    std::vector<marl_params> params;
+    std::vector<DevConsts> hconsts;
+    std::vector<double> extra;  // per instance: delta_x, auxcon, rhorat0, F_fixed (not needed on device)
+    DevConsts* dconsts = nullptr;
+    // device scratch (grown on demand)
+    double* buf[4] = {nullptr, nullptr, nullptr, nullptr};  // Y0, Y1, F0, F1 (or staging)
+    size_t buf_cap[4] = {0, 0, 0, 0};
+    double* part = nullptr;
+    size_t part_cap = 0;
+    double* rec = nullptr;  // [batch][NQ]
+    Rk45Ctrl* dctrl = nullptr;
+    Rk45Ctrl* hctrl = nullptr;  // pinned
+    double* hrec = nullptr;     // pinned [batch][NQ]
+    double* ddt = nullptr;      // [batch] per-instance dt
+    // options
+    int64_t rk4_variant = -1, rk45_variant = -1, sweep_variant = -1, host_layout = LAYOUT_TILED, poll = 64;
+    std::string err;
+};
+
+static int fail(marl_ctx* ctx, int code, const char* fmt, ...)
+{
+    char msg[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(msg, sizeof msg, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIP_OK(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) return fail(ctx, -100 - (int)e_, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+#define LAUNCH_OK(ctx)                                                                            \
+    do {                                                                                          \
+        hipError_t e_ = hipGetLastError();                                                        \
+        if (e_ != hipSuccess) return fail(ctx, -100 - (int)e_, "kernel launch failed: %s", hipGetErrorString(e_)); \
+    } while (0)
+
+// ----------------------------------------------------------------------------------------------
+// Derived constants: LMAHeureuxPorosityDiff.__init__, marlpde/LHeureux_model.py:23-24, :36-72,
+// :87-88, :130-133; depth mask: marlpde/Evolve_scenario.py:51-54.
+// ----------------------------------------------------------------------------------------------
+static void derive_consts(const marl_params& p, int64_t N, DevConsts& c, double extra[4])
+{
+    const double g = 100 * 9.81;
+    const double dx = p.length / (double)N;
+    const double delta_x = (0.0 + 1.5 * dx) - (0.0 + 0.5 * dx);  // x[1] - x[0] of the cell centres (:23-24)
+    const double dCa = p.DCa / p.D0Ca, dCO3 = p.DCO3 / p.D0Ca;
+    const double auxcon = p.beta / (p.D0Ca * p.b * g * p.rhow * (p.PhiNR - p.PhiInfty));
+    const double rhorat0 = (p.rhos0 / p.rhow - 1) * p.beta / p.sedimentationrate;
+    const double F_fixed = 1 - std::exp(10 - 10 / p.PhiIni);
+    memset(&c, 0, sizeof c);
+    c.inv_dx = 1.0 / dx;
+    c.inv_dx2 = std::pow(dx, -2);
+    c.dCa = dCa;
+    c.dCO3 = dCO3;
+    c.dPhi = auxcon * F_fixed * std::pow(p.PhiIni, 3) / (1 - p.PhiIni);
+    c.pe_cCa = delta_x / (2. * dCa);
+    c.pe_cCO3 = delta_x / (2. * dCO3);
+    c.pe_Phi = delta_x / (2. * c.dPhi);
+    c.presum = 1 - rhorat0 * std::pow(p.Phi0, 3) * (1 - std::exp(10 - 10 / p.Phi0)) / (1 - p.Phi0);
+    c.rhorat = (p.rhos / p.rhow - 1) * p.beta / p.sedimentationrate;
+    c.KRat = p.KC / p.KA;
+    c.nu1 = p.k1 / p.k2;
+    c.nu2 = p.k4 / p.k3;
+    c.m1 = p.m1; c.m2 = p.m2; c.n1 = p.n1; c.n2 = p.n2;
+    c.p0_m1 = std::pow(0.0, p.m1); c.p0_m2 = std::pow(0.0, p.m2);
+    c.p0_n1 = std::pow(0.0, p.n1); c.p0_n2 = std::pow(0.0, p.n2);
+    c.lambda_ = p.k3 / p.k2;
+    c.Da = p.k2 * p.Tstar;
+    c.delta = p.rhos / (p.muA * std::sqrt(p.KC));
+    const double bc[NF] = {p.CA0, p.CC0, p.cCa0, p.cCO30, p.Phi0};
+    for (int f = 0; f < NF; f++) c.bc[f] = bc[f];
+    c.pe_min = 1e-2;
+    c.pe_max = 1 / c.pe_min;
+    c.N = N;
+    c.fv = p.FV_switch;
+    // mask = H(x - shallow) * H(deep - x) with H(0) = 0 at the cell centres: a contiguous index range
+    int64_t lo = N, hi = N;
+    bool open = false;
+    for (int64_t i = 0; i < N; i++) {
+        const double x = 0.0 + ((double)i + 0.5) * dx;
+        const bool in = (x - p.shallow_limit > 0) && (p.deep_limit - x > 0);
+        if (in && !open) { lo = i; open = true; }
+        if (!in && open) { hi = i; break; }
+    }
+    if (!open) lo = hi = 0;
+    c.mask_lo = lo;
+    c.mask_hi = hi;
+    extra[0] = delta_x; extra[1] = auxcon; extra[2] = rhorat0; extra[3] = F_fixed;
+}
+
+static int ensure(marl_ctx* ctx, int which, size_t doubles)
+{
+    if (ctx->buf_cap[which] >= doubles) return 0;
+    if (ctx->buf[which]) HIP_OK(ctx, hipFree(ctx->buf[which]));
+    ctx->buf[which] = nullptr;
+    ctx->buf_cap[which] = 0;
+    HIP_OK(ctx, hipMalloc((void**)&ctx->buf[which], doubles * sizeof(double)));
+    ctx->buf_cap[which] = doubles;
+    return 0;
+}
+
+static int ensure_part(marl_ctx* ctx, size_t records)
+{
+    if (ctx->part_cap >= records) return 0;
+    if (ctx->part) HIP_OK(ctx, hipFree(ctx->part));
+    ctx->part = nullptr;
+    ctx->part_cap = 0;
+    HIP_OK(ctx, hipMalloc((void**)&ctx->part, records * NQ * sizeof(double)));
+    ctx->part_cap = records;
+    return 0;
+}
+
+static int64_t state_doubles(int64_t n, int layout)
+{
+    return layout == LAYOUT_TILED ? ((n + 63) / 64) * (int64_t)(NF * 64) : (int64_t)NF * n;
+}
+
+extern "C" {
+
+int marl_ctx_create(const marl_params* params, int64_t n_instances, int64_t N, int device, marl_ctx** out)
+{
+    if (!params || !out || n_instances < 1 || N < 2) return fail(nullptr, -1, "marl_ctx_create: invalid argument");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(nullptr, -2, "marl_ctx_create: no HIP device (%s); this library has no CPU path", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(nullptr, -1, "marl_ctx_create: device %d out of range (0..%d)", device, ndev - 1);
+    marl_ctx* ctx = new marl_ctx;
+    ctx->device = device;
+    ctx->N = N;
+    ctx->batch = n_instances;
+    ctx->slab = Slab{N, 0, N, 0, N};
+    ctx->params.assign(params, params + n_instances);
+    ctx->hconsts.resize(n_instances);
+    ctx->extra.resize(4 * n_instances);
+    for (int64_t b = 0; b < n_instances; b++) {
+        const marl_params& p = params[b];
+        if (!(p.length > 0)) { delete ctx; return fail(nullptr, -1, "marl_ctx_create: instance %lld: length must be > 0", (long long)b); }
+        derive_consts(p, N, ctx->hconsts[b], &ctx->extra[4 * b]);
+    }
+#define CREATE_OK(call)                                                                     \
+    do {                                                                                    \
+        hipError_t e2_ = (call);                                                            \
+        if (e2_ != hipSuccess) {                                                            \
+            fail(nullptr, -100 - (int)e2_, "%s failed: %s", #call, hipGetErrorString(e2_)); \
+            marl_ctx_destroy(ctx);                                                          \
+            return -100 - (int)e2_;                                                         \
+        }                                                                                   \
+    } while (0)
+    CREATE_OK(hipSetDevice(device));
+    CREATE_OK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    CREATE_OK(hipMalloc((void**)&ctx->dconsts, sizeof(DevConsts) * n_instances));
+    CREATE_OK(hipMemcpy(ctx->dconsts, ctx->hconsts.data(), sizeof(DevConsts) * n_instances, hipMemcpyHostToDevice));
+    CREATE_OK(hipMalloc((void**)&ctx->rec, sizeof(double) * NQ * n_instances));
+    CREATE_OK(hipMalloc((void**)&ctx->dctrl, sizeof(Rk45Ctrl) * n_instances));
+    CREATE_OK(hipMalloc((void**)&ctx->ddt, sizeof(double) * n_instances));
+    CREATE_OK(hipHostMalloc((void**)&ctx->hctrl, sizeof(Rk45Ctrl) * n_instances, hipHostMallocDefault));
+    CREATE_OK(hipHostMalloc((void**)&ctx->hrec, sizeof(double) * NQ * n_instances, hipHostMallocDefault));
+#undef CREATE_OK
+    *out = ctx;
+    return 0;
+}
+
+void marl_ctx_destroy(marl_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    for (int i = 0; i < 4; i++)
+        if (ctx->buf[i]) (void)hipFree(ctx->buf[i]);
+    if (ctx->part) (void)hipFree(ctx->part);
+    if (ctx->rec) (void)hipFree(ctx->rec);
+    if (ctx->dctrl) (void)hipFree(ctx->dctrl);
+    if (ctx->ddt) (void)hipFree(ctx->ddt);
+    if (ctx->dconsts) (void)hipFree(ctx->dconsts);
+    if (ctx->hctrl) (void)hipHostFree(ctx->hctrl);
+    if (ctx->hrec) (void)hipHostFree(ctx->hrec);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char* marl_last_error(const marl_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int marl_set_stream(marl_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return -1;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return 0;
+}
+
+int marl_synchronize(marl_ctx* ctx)
+{
+    if (!ctx) return -1;
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int marl_set_option(marl_ctx* ctx, const char* name, int64_t value)
+{
+    if (!ctx || !name) return -1;
+    const std::string n(name);
+    if (n == "rk4_variant") ctx->rk4_variant = value;
+    else if (n == "rk45_variant") ctx->rk45_variant = value;
+    else if (n == "sweep_variant") ctx->sweep_variant = value;
+    else if (n == "host_layout") ctx->host_layout = value ? LAYOUT_TILED : LAYOUT_FIELD_MAJOR;
+    else if (n == "poll_interval") ctx->poll = value > 0 ? value : 1;
+    else return fail(ctx, -1, "marl_set_option: unknown option '%s'", name);
+    return 0;
+}
+
+int marl_get_constants(const marl_ctx* ctx, int64_t inst, double out[19])
+{
+    if (!ctx || inst < 0 || inst >= ctx->batch || !out) return -1;
+    const DevConsts& c = ctx->hconsts[inst];
+    const double* x = &ctx->extra[4 * inst];
+    const double v[19] = {x[0], c.nu1, c.nu2, c.KRat, c.dCa, c.dCO3, c.delta, c.Da, c.lambda_, x[1], x[2], c.rhorat,
+                          c.presum, x[3], c.dPhi, c.pe_min, c.pe_max, (double)c.mask_lo, (double)c.mask_hi};
+    memcpy(out, v, sizeof v);
+    return 0;
+}
+
+int64_t marl_state_doubles(const marl_ctx* ctx, int layout) { return ctx ? state_doubles(ctx->slab.n_buf, layout) : -1; }
+
+}  // extern "C"
+
+// ----------------------------------------------------------------------------------------------
+// launch helpers
+// ----------------------------------------------------------------------------------------------
+static inline int64_t inst_stride(const marl_ctx* ctx, int layout) { return state_doubles(ctx->slab.n_buf, layout); }
+
+static int launch_rhs(marl_ctx* ctx, const double* y, double* dydt, int layout)
+{
+    const dim3 grid((unsigned)((ctx->slab.n_buf + 255) / 256), (unsigned)ctx->batch);
+    if (layout == LAYOUT_TILED)
+        hipLaunchKernelGGL(rhs_kernel<LAYOUT_TILED>, grid, dim3(256), 0, ctx->stream, y, dydt, ctx->dconsts, ctx->slab, inst_stride(ctx, layout));
+    else
+        hipLaunchKernelGGL(rhs_kernel<LAYOUT_FIELD_MAJOR>, grid, dim3(256), 0, ctx->stream, y, dydt, ctx->dconsts, ctx->slab, inst_stride(ctx, layout));
+    LAUNCH_OK(ctx);
+    return 0;
+}
+
+static int launch_convert(marl_ctx* ctx, const double* src, double* dst, int sl, int dl)
+{
+    const int64_t n = ctx->slab.n_buf;
+    if (sl == dl) {
+        HIP_OK(ctx, hipMemcpyAsync(dst, src, sizeof(double) * state_doubles(n, sl) * ctx->batch, hipMemcpyDeviceToDevice, ctx->stream));
+        return 0;
+    }
+    const dim3 grid((unsigned)((n + 255) / 256), (unsigned)ctx->batch);
+    if (sl == LAYOUT_FIELD_MAJOR)
+        hipLaunchKernelGGL((convert_kernel<LAYOUT_FIELD_MAJOR, LAYOUT_TILED>), grid, dim3(256), 0, ctx->stream, src, dst, n,
+                           ctx->slab.ld, (int64_t)0, state_doubles(n, sl), state_doubles(n, dl));
+    else
+        hipLaunchKernelGGL((convert_kernel<LAYOUT_TILED, LAYOUT_FIELD_MAJOR>), grid, dim3(256), 0, ctx->stream, src, dst, n,
+                           (int64_t)0, ctx->slab.ld, state_doubles(n, sl), state_doubles(n, dl));
+    LAUNCH_OK(ctx);
+    return 0;
+}
+
+// monitors of `y` -> ctx->rec[batch][NQ] (device)
+static int launch_monitors(marl_ctx* ctx, const double* y, int layout)
+{
+    const int64_t n = ctx->slab.out_hi - ctx->slab.out_lo;
+    int64_t nb = (n + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    if (int rc = ensure_part(ctx, (size_t)(nb * ctx->batch))) return rc;
+    const dim3 grid((unsigned)nb, (unsigned)ctx->batch);
+    if (layout == LAYOUT_TILED)
+        hipLaunchKernelGGL(monitors_kernel<LAYOUT_TILED>, grid, dim3(256), 0, ctx->stream, y, ctx->dconsts, ctx->slab, inst_stride(ctx, layout), ctx->part);
+    else
+        hipLaunchKernelGGL(monitors_kernel<LAYOUT_FIELD_MAJOR>, grid, dim3(256), 0, ctx->stream, y, ctx->dconsts, ctx->slab, inst_stride(ctx, layout), ctx->part);
+    LAUNCH_OK(ctx);
+    hipLaunchKernelGGL(reduce_records_kernel, dim3((unsigned)ctx->batch), dim3(256), 0, ctx->stream, ctx->part, nb, ctx->rec);
+    LAUNCH_OK(ctx);
+    return 0;
+}
+
+static void record_to_events(const double* r, double* g)
+{
+    g[0] = r[1]; g[1] = r[2]; g[2] = r[3]; g[3] = r[5] - 1.0; g[4] = r[6] - 1.0; g[5] = r[4]; g[6] = r[7];
+}
+
+// ---- fused RK4 variants ------------------------------------------------------------------------
+struct Rk4Variant { int blk, cpt, nsteps; };
+static const Rk4Variant kRk4Variants[] = {
+    {256, 1, 1}, {256, 1, 2}, {256, 2, 1}, {256, 2, 2}, {128, 1, 4}, {128, 1, 8}, {256, 2, 4}, {512, 1, 1}, {256, 4, 1}, {128, 1, 1},
+};
+constexpr int kNumRk4Variants = sizeof(kRk4Variants) / sizeof(kRk4Variants[0]);
+
+template <int BLK, int CPT, int NSTEPS>
+static void launch_rk4_t(marl_ctx* ctx, const double* yin, double* yout, int layout, double dt)
+{
+    constexpr int V = BLK * CPT - 8 * NSTEPS;
+    const int64_t n = ctx->slab.out_hi - ctx->slab.out_lo;
+    const dim3 grid((unsigned)((n + V - 1) / V));
+    if (layout == LAYOUT_TILED)
+        hipLaunchKernelGGL((rk4_fused_kernel<BLK, CPT, LAYOUT_TILED, NSTEPS>), grid, dim3(BLK), 0, ctx->stream, yin, yout, ctx->dconsts, ctx->slab, dt);
+    else
+        hipLaunchKernelGGL((rk4_fused_kernel<BLK, CPT, LAYOUT_FIELD_MAJOR, NSTEPS>), grid, dim3(BLK), 0, ctx->stream, yin, yout, ctx->dconsts, ctx->slab, dt);
+}
+
+static int launch_rk4(marl_ctx* ctx, int v, bool single, const double* yin, double* yout, int layout, double dt)
+{
+    const Rk4Variant& rv = kRk4Variants[v];
+    const int key = rv.blk * 1000 + rv.cpt * 100 + (single ? 1 : rv.nsteps);
+    switch (key) {
+        case 256101: launch_rk4_t<256, 1, 1>(ctx, yin, yout, layout, dt); break;
+        case 256102: launch_rk4_t<256, 1, 2>(ctx, yin, yout, layout, dt); break;
+        case 256201: launch_rk4_t<256, 2, 1>(ctx, yin, yout, layout, dt); break;
+        case 256202: launch_rk4_t<256, 2, 2>(ctx, yin, yout, layout, dt); break;
+        case 256204: launch_rk4_t<256, 2, 4>(ctx, yin, yout, layout, dt); break;
+        case 128101: launch_rk4_t<128, 1, 1>(ctx, yin, yout, layout, dt); break;
+        case 128104: launch_rk4_t<128, 1, 4>(ctx, yin, yout, layout, dt); break;
+        case 128108: launch_rk4_t<128, 1, 8>(ctx, yin, yout, layout, dt); break;
+        case 512101: launch_rk4_t<512, 1, 1>(ctx, yin, yout, layout, dt); break;
+        case 256401: launch_rk4_t<256, 4, 1>(ctx, yin, yout, layout, dt); break;
+        default: return fail(ctx, -1, "rk4 variant %d not instantiated", v);
+    }
+    LAUNCH_OK(ctx);
+    return 0;
+}
+
+static int default_rk4_variant(const marl_ctx* ctx)
+{
+    if (ctx->rk4_variant >= 0 && ctx->rk4_variant < kNumRk4Variants) return (int)ctx->rk4_variant;
+    const int64_t n = ctx->slab.out_hi - ctx->slab.out_lo;
+    return n <= 131072 ? 5 : 2;  // small grids: deep temporal fusion (launch bound); large: 2 cells/thread
+}
+
+// y (device, `layout`) advanced in place; `tmp` is a second buffer of the same size
+static int rk4_run(marl_ctx* ctx, double* y, double* tmp, int layout, double dt, int64_t nsteps)
+{
+    const int v = default_rk4_variant(ctx);
+    const int per = kRk4Variants[v].nsteps;
+    double* a = y;
+    double* b = tmp;
+    int64_t left = nsteps;
+    while (left >= per) {
+        if (int rc = launch_rk4(ctx, v, false, a, b, layout, dt)) return rc;
+        std::swap(a, b);
+        left -= per;
+    }
+    while (left > 0) {
+        if (int rc = launch_rk4(ctx, v, true, a, b, layout, dt)) return rc;
+        std::swap(a, b);
+        left--;
+    }
+    if (a != y) HIP_OK(ctx, hipMemcpyAsync(y, a, sizeof(double) * state_doubles(ctx->slab.n_buf, layout), hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+
+// ---- sweep variants ----------------------------------------------------------------------------
+struct SweepVariant { int blk, cpt; };
+static const SweepVariant kSweepVariants[] = {{256, 4}, {512, 2}, {1024, 1}, {256, 1}, {128, 2}, {64, 4}, {256, 2}, {128, 4}, {512, 1}};
+constexpr int kNumSweepVariants = sizeof(kSweepVariants) / sizeof(kSweepVariants[0]);
+
+static int default_sweep_variant(marl_ctx* ctx)
+{
+    if (ctx->sweep_variant >= 0 && ctx->sweep_variant < kNumSweepVariants) {
+        const SweepVariant& sv = kSweepVariants[ctx->sweep_variant];
+        if ((int64_t)sv.blk * sv.cpt >= ctx->N) return (int)ctx->sweep_variant;
+    }
+    const int order[] = {3, 4, 5, 8, 6, 7, 0, 1, 2};  // smallest window first
+    int best = -1;
+    int64_t best_win = 0;
+    for (int i : order) {
+        const int64_t win = (int64_t)kSweepVariants[i].blk * kSweepVariants[i].cpt;
+        if (win >= ctx->N && (best < 0 || win < best_win)) { best = i; best_win = win; }
+    }
+    return best;
+}
+
+#define SWEEP_DISPATCH(KERNEL, ...)                                                                           \
+    switch (v) {                                                                                              \
+        case 0: hipLaunchKernelGGL((KERNEL<256, 4>), grid, dim3(256), 0, ctx->stream, __VA_ARGS__); break;    \
+        case 1: hipLaunchKernelGGL((KERNEL<512, 2>), grid, dim3(512), 0, ctx->stream, __VA_ARGS__); break;    \
+        case 2: hipLaunchKernelGGL((KERNEL<1024, 1>), grid, dim3(1024), 0, ctx->stream, __VA_ARGS__); break;  \
+        case 3: hipLaunchKernelGGL((KERNEL<256, 1>), grid, dim3(256), 0, ctx->stream, __VA_ARGS__); break;    \
+        case 4: hipLaunchKernelGGL((KERNEL<128, 2>), grid, dim3(128), 0, ctx->stream, __VA_ARGS__); break;    \
+        case 5: hipLaunchKernelGGL((KERNEL<64, 4>), grid, dim3(64), 0, ctx->stream, __VA_ARGS__); break;      \
+        case 6: hipLaunchKernelGGL((KERNEL<256, 2>), grid, dim3(256), 0, ctx->stream, __VA_ARGS__); break;    \
+        case 7: hipLaunchKernelGGL((KERNEL<128, 4>), grid, dim3(128), 0, ctx->stream, __VA_ARGS__); break;    \
+        case 8: hipLaunchKernelGGL((KERNEL<512, 1>), grid, dim3(512), 0, ctx->stream, __VA_ARGS__); break;    \
+        default: return fail(ctx, -1, "sweep variant %d not instantiated", v);                                \
+    }
+
+// ---- fused RK45 variants -----------------------------------------------------------------------
+struct Rk45Variant { int blk, cpt; };
+static const Rk45Variant kRk45Variants[] = {{256, 1}, {256, 2}, {512, 1}, {128, 1}};
+constexpr int kNumRk45Variants = sizeof(kRk45Variants) / sizeof(kRk45Variants[0]);
+
+static int default_rk45_variant(const marl_ctx* ctx)
+{
+    if (ctx->rk45_variant >= 0 && ctx->rk45_variant < kNumRk45Variants) return (int)ctx->rk45_variant;
+    return 0;
+}
+
+static int64_t rk45_blocks(const marl_ctx* ctx, int v)
+{
+    const int V = kRk45Variants[v].blk * kRk45Variants[v].cpt - 12;
+    const int64_t n = ctx->slab.out_hi - ctx->slab.out_lo;
+    return (n + V - 1) / V;
+}
+
+template <int BLK, int CPT>
+static void launch_attempt_t(marl_ctx* ctx, int64_t nb, int layout)
+{
+    if (layout == LAYOUT_TILED)
+        hipLaunchKernelGGL((rk45_attempt_kernel<BLK, CPT, LAYOUT_TILED>), dim3((unsigned)nb), dim3(BLK), 0, ctx->stream, ctx->buf[0], ctx->buf[1],
+                           ctx->buf[2], ctx->buf[3], ctx->dconsts, ctx->slab, ctx->dctrl, ctx->part);
+    else
+        hipLaunchKernelGGL((rk45_attempt_kernel<BLK, CPT, LAYOUT_FIELD_MAJOR>), dim3((unsigned)nb), dim3(BLK), 0, ctx->stream, ctx->buf[0],
+                           ctx->buf[1], ctx->buf[2], ctx->buf[3], ctx->dconsts, ctx->slab, ctx->dctrl, ctx->part);
+}
+
+static int launch_attempt(marl_ctx* ctx, int v, int layout)
+{
+    const int64_t nb = rk45_blocks(ctx, v);
+    switch (v) {
+        case 0: launch_attempt_t<256, 1>(ctx, nb, layout); break;
+        case 1: launch_attempt_t<256, 2>(ctx, nb, layout); break;
+        case 2: launch_attempt_t<512, 1>(ctx, nb, layout); break;
+        case 3: launch_attempt_t<128, 1>(ctx, nb, layout); break;
+        default: return fail(ctx, -1, "rk45 variant %d not instantiated", v);
+    }
+    LAUNCH_OK(ctx);
+    hipLaunchKernelGGL(rk45_control_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->part, nb, ctx->dctrl);
+    LAUNCH_OK(ctx);
+    return 0;
+}
+
+template <int BLK, int CPT>
+static void launch_dense_t(marl_ctx* ctx, int64_t nb, int layout, const double* yold, const double* fold, double h,
+                           const DenseWeights& dw, double* yout)
+{
+    if (layout == LAYOUT_TILED)
+        hipLaunchKernelGGL((rk45_dense_kernel<BLK, CPT, LAYOUT_TILED>), dim3((unsigned)nb), dim3(BLK), 0, ctx->stream, yold, fold, ctx->dconsts,
+                           ctx->slab, h, dw, yout, ctx->part);
+    else
+        hipLaunchKernelGGL((rk45_dense_kernel<BLK, CPT, LAYOUT_FIELD_MAJOR>), dim3((unsigned)nb), dim3(BLK), 0, ctx->stream, yold, fold,
+                           ctx->dconsts, ctx->slab, h, dw, yout, ctx->part);
+}
+
+// Dense output P (scipy/integrate/_ivp/rk.py:393-407): w_j(x) = sum_m P[j][m] x^(m+1)
+static const double kDpP[7][4] = {
+    {1, -8048581381.0 / 2820520608, 8663915743.0 / 2820520608, -12715105075.0 / 11282082432},
+    {0, 0, 0, 0},
+    {0, 131558114200.0 / 32700410799, -68118460800.0 / 10900136933, 87487479700.0 / 32700410799},
+    {0, -1754552775.0 / 470086768, 14199869525.0 / 1410260304, -10690763975.0 / 1880347072},
+    {0, 127303824393.0 / 49829197408, -318862633887.0 / 49829197408, 701980252875.0 / 199316789632},
+    {0, -282668133.0 / 205662961, 2019193451.0 / 616988883, -1453857185.0 / 822651844},
+    {0, 40617522.0 / 29380423, -110615467.0 / 29380423, 69997945.0 / 29380423}};
+
+// Evaluate the dense output of the LAST accepted step at time t: state into yout (may be NULL) and the
+// seven monitors into g (may be NULL; synchronises when given).
+static int dense_eval(marl_ctx* ctx, int v, int layout, bool small, const Rk45Ctrl& c, double t, double* yout, double* g)
+{
+    const double x = (t - c.t_old) / c.h_prev;
+    DenseWeights dw;
+    double pw[4] = {x, x * x, x * x * x, x * x * x * x};
+    for (int j = 0; j < 7; j++) {
+        double a = 0;
+        for (int m = 0; m < 4; m++) a += kDpP[j][m] * pw[m];
+        dw.w[j] = a;
+    }
+    const double* yold = small ? ctx->buf[1] : ctx->buf[c.cur ^ 1];
+    const double* fold = small ? ctx->buf[3] : ctx->buf[2 + (c.cur ^ 1)];
+    const int64_t nb = rk45_blocks(ctx, v);
+    switch (v) {
+        case 0: launch_dense_t<256, 1>(ctx, nb, layout, yold, fold, c.h_prev, dw, yout); break;
+        case 1: launch_dense_t<256, 2>(ctx, nb, layout, yold, fold, c.h_prev, dw, yout); break;
+        case 2: launch_dense_t<512, 1>(ctx, nb, layout, yold, fold, c.h_prev, dw, yout); break;
+        case 3: launch_dense_t<128, 1>(ctx, nb, layout, yold, fold, c.h_prev, dw, yout); break;
+        default: return fail(ctx, -1, "rk45 variant %d not instantiated", v);
+    }
+    LAUNCH_OK(ctx);
+    if (g) {
+        hipLaunchKernelGGL(reduce_records_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->part, nb, ctx->rec);
+        LAUNCH_OK(ctx);
+        HIP_OK(ctx, hipMemcpyAsync(ctx->hrec, ctx->rec, sizeof(double) * NQ, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+        record_to_events(ctx->hrec, g);
+    }
+    return 0;
+}
+
+// Brent's method for monitor `e` on the last accepted step (solve_event_equation, ivp.py:51-76)
+static int brent_event(marl_ctx* ctx, int v, int layout, bool small, const Rk45Ctrl& c, int e, double ga, double gb, double* root)
+{
+    const double xtol = 4 * 2.220446049250313e-16, rtol = xtol;
+    double a = c.t_old, b = c.t, fa = ga, fb = gb, g[7];
+    if (fa == 0) { *root = a; return 0; }
+    if (fb == 0) { *root = b; return 0; }
+    double xpre = a, xcur = b, fpre = fa, fcur = fb, xblk = 0, fblk = 0, spre = 0, scur = 0;
+    for (int it = 0; it < 100; it++) {
+        if (fpre != 0 && fcur != 0 && ((fpre < 0) != (fcur < 0))) { xblk = xpre; fblk = fpre; spre = scur = xcur - xpre; }
+        if (std::fabs(fblk) < std::fabs(fcur)) { xpre = xcur; xcur = xblk; xblk = xpre; fpre = fcur; fcur = fblk; fblk = fpre; }
+        const double delta = (xtol + rtol * std::fabs(xcur)) / 2, sbis = (xblk - xcur) / 2;
+        if (fcur == 0 || std::fabs(sbis) < delta) break;
+        if (std::fabs(spre) > delta && std::fabs(fcur) < std::fabs(fpre)) {
+            double stry;
+            if (xpre == xblk) stry = -fcur * (xcur - xpre) / (fcur - fpre);
+            else {
+                const double dpre = (fpre - fcur) / (xpre - xcur), dblk = (fblk - fcur) / (xblk - xcur);
+                stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
+            }
+            if (2 * std::fabs(stry) < std::fmin(std::fabs(spre), 3 * std::fabs(sbis) - delta)) { spre = scur; scur = stry; }
+            else { spre = sbis; scur = sbis; }
+        } else { spre = sbis; scur = sbis; }
+        xpre = xcur; fpre = fcur;
+        if (std::fabs(scur) > delta) xcur += scur; else xcur += (sbis > 0 ? delta : -delta);
+        if (int rc = dense_eval(ctx, v, layout, small, c, xcur, nullptr, g)) return rc;
+        fcur = g[e];
+    }
+    *root = xcur;
+    return 0;
+}
+
+static void ctrl_to_stats(const Rk45Ctrl& c, marl_stats* st)
+{
+    memset(st, 0, sizeof *st);
+    st->nfev = c.nfev;
+    st->n_accepted = c.n_acc;
+    st->n_rejected = c.n_rej;
+    st->status = c.status;
+    st->t = c.t;
+    st->h_next = c.h_abs;
+    for (int e = 0; e < 7; e++) { st->event_value[e] = c.g[e]; st->n_events[e] = c.n_events[e]; }
+}
+
+// The adaptive loop on device buffers buf[0..3] (`layout`), state already in buf[0].
+// small = true: the grid fits one workgroup -> the persistent sweep kernel runs all attempts on-chip
+// (state in buf[0], FIELD-MAJOR; (y_old, f_old) of a paused step in buf[1], buf[3]).
+static int rk45_run(marl_ctx* ctx, int layout, bool small, double t0, double t1, double first_step, double rtol, double atol,
+                    const double* t_eval, int64_t n_eval, double* y_eval_dev, double* t_events, int64_t max_events,
+                    int64_t max_attempts, marl_stats* stats)
+{
+    if (!(first_step > 0) || !(t1 >= t0)) return fail(ctx, -1, "rk45: need first_step > 0 and t1 >= t0 (forward integration)");
+    if (t1 > t0 && first_step > t1 - t0) return fail(ctx, -1, "rk45: `first_step` exceeds bounds");  // common.py:10-16
+    if (!(rtol > 0) || !(atol >= 0)) return fail(ctx, -1, "rk45: tolerances must be positive");
+    for (int64_t i = 0; i < n_eval; i++)
+        if (t_eval[i] < t0 || t_eval[i] > t1 || (i > 0 && t_eval[i] <= t_eval[i - 1]))
+            return fail(ctx, -1, "rk45: `t_eval` must be sorted and within t_span");  // ivp.py:603-609
+    const int v = small ? 0 : default_rk45_variant(ctx);
+    const int sv = small ? default_sweep_variant(ctx) : -1;
+    const int64_t nb = rk45_blocks(ctx, v);
+    if (int rc = ensure_part(ctx, (size_t)std::max<int64_t>(nb, 1024))) return rc;
+    const int64_t sd = state_doubles(ctx->slab.n_buf, layout);
+    // f(t0, y0) and the monitors at t0
+    if (!small)
+        if (int rc = launch_rhs(ctx, ctx->buf[0], ctx->buf[2], layout)) return rc;
+    if (int rc = launch_monitors(ctx, ctx->buf[0], layout)) return rc;
+    hipLaunchKernelGGL(rk45_init_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->dctrl, ctx->rec, t0, t1, first_step, rtol, atol,
+                       (int64_t)NF * ctx->N, max_attempts, 0);
+    LAUNCH_OK(ctx);
+    int64_t eval_i = 0;
+    // t_eval == t0 is emitted on the first step by scipy (dense output at x = 0 == y_old)
+    const bool events_on = t_events != nullptr && max_events > 0;
+    auto next_pause = [&]() { return eval_i < n_eval ? t_eval[eval_i] : (double)INFINITY; };
+    hipLaunchKernelGGL(rk45_resume_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->dctrl, next_pause(), max_attempts);
+    LAUNCH_OK(ctx);
+    if (events_on) {
+        // pause_on_event is a plain field: set it through a tiny host round trip once
+        HIP_OK(ctx, hipMemcpyAsync(ctx->hctrl, ctx->dctrl, sizeof(Rk45Ctrl), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->hctrl->pause_on_event = 1;
+        HIP_OK(ctx, hipMemcpyAsync(ctx->dctrl, ctx->hctrl, sizeof(Rk45Ctrl), hipMemcpyHostToDevice, ctx->stream));
+    }
+    int64_t seen_events[7] = {0, 0, 0, 0, 0, 0, 0};
+    Rk45Ctrl& hc = *ctx->hctrl;
+    while (true) {
+        if (small) {
+            const int v = sv;  // SWEEP_DISPATCH switches on `v`
+            const dim3 grid(1);
+            SWEEP_DISPATCH(rk45_sweep_kernel, ctx->buf[0], ctx->dconsts, ctx->dctrl, ctx->N, ctx->buf[1], ctx->buf[3])
+            LAUNCH_OK(ctx);
+        } else {
+            for (int64_t i = 0; i < ctx->poll; i++)
+                if (int rc = launch_attempt(ctx, v, layout)) return rc;
+        }
+        HIP_OK(ctx, hipMemcpyAsync(ctx->hctrl, ctx->dctrl, sizeof(Rk45Ctrl), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+        if (hc.status == ST_RUNNING) continue;
+        const bool stepped = hc.n_acc > 0;
+        // event roots inside the last accepted step (ivp.py:673-694)
+        if (events_on && stepped) {
+            for (int e = 0; e < 7; e++) {
+                if (hc.n_events[e] > seen_events[e]) {
+                    // only the newest sign change can be refined (earlier ones were refined at their own pause)
+                    double ga[7];
+                    if (int rc = dense_eval(ctx, v, layout, small, hc, hc.t_old, nullptr, ga)) return rc;
+                    double root = hc.ev_last[e];
+                    if (int rc = brent_event(ctx, v, layout, small, hc, e, ga[e], hc.g[e], &root)) return rc;
+                    for (int64_t k = seen_events[e]; k < hc.n_events[e]; k++)
+                        if (k < max_events) t_events[e * max_events + k] = root;
+                    seen_events[e] = hc.n_events[e];
+                }
+            }
+        }
+        // t_eval samples inside (t_old, t]  (ivp.py:706-723)
+        if (stepped) {
+            while (eval_i < n_eval && t_eval[eval_i] <= hc.t) {
+                double* dst = y_eval_dev + eval_i * sd;
+                if (t_eval[eval_i] <= hc.t_old && hc.n_acc == 1 && t_eval[eval_i] == t0) {
+                    HIP_OK(ctx, hipMemcpyAsync(dst, small ? ctx->buf[1] : ctx->buf[hc.cur ^ 1], sizeof(double) * sd, hipMemcpyDeviceToDevice, ctx->stream));
+                } else if (int rc = dense_eval(ctx, v, layout, small, hc, t_eval[eval_i], dst, nullptr)) return rc;
+                eval_i++;
+            }
+        } else {
+            while (eval_i < n_eval && t_eval[eval_i] <= hc.t) {  // t0 == t1: no step was taken
+                HIP_OK(ctx, hipMemcpyAsync(y_eval_dev + eval_i * sd, ctx->buf[small ? 0 : hc.cur], sizeof(double) * sd, hipMemcpyDeviceToDevice, ctx->stream));
+                eval_i++;
+            }
+        }
+        if (hc.status != ST_PAUSED) break;
+        hipLaunchKernelGGL(rk45_resume_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->dctrl, next_pause(), max_attempts);
+        LAUNCH_OK(ctx);
+    }
+    ctrl_to_stats(hc, stats);
+    if (!small && hc.cur != 0) {
+        HIP_OK(ctx, hipMemcpyAsync(ctx->buf[0], ctx->buf[1], sizeof(double) * sd, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_OK(ctx, hipMemcpyAsync(ctx->buf[2], ctx->buf[3], sizeof(double) * sd, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" {
+
+int marl_rhs_dev(marl_ctx* ctx, double t, const double* y_dev, double* dydt_dev, int layout)
+{
+    (void)t;
+    if (!ctx || !y_dev || !dydt_dev || y_dev == dydt_dev) return ctx ? fail(ctx, -1, "marl_rhs_dev: invalid argument") : -1;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    return launch_rhs(ctx, y_dev, dydt_dev, layout);
+}
+
+int marl_rhs(marl_ctx* ctx, double t, const double* y, double* dydt)
+{
+    (void)t;
+    if (!ctx || !y || !dydt) return ctx ? fail(ctx, -1, "marl_rhs: invalid argument") : -1;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)NF * ctx->N * ctx->batch;
+    if (int rc = ensure(ctx, 0, n)) return rc;
+    if (int rc = ensure(ctx, 1, n)) return rc;
+    HIP_OK(ctx, hipMemcpyAsync(ctx->buf[0], y, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = launch_rhs(ctx, ctx->buf[0], ctx->buf[1], LAYOUT_FIELD_MAJOR)) return rc;
+    HIP_OK(ctx, hipMemcpyAsync(dydt, ctx->buf[1], n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int marl_events_dev(marl_ctx* ctx, const double* y_dev, int layout, double* out)
+{
+    if (!ctx || !y_dev || !out) return ctx ? fail(ctx, -1, "marl_events_dev: invalid argument") : -1;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    if (int rc = launch_monitors(ctx, y_dev, layout)) return rc;
+    HIP_OK(ctx, hipMemcpyAsync(ctx->hrec, ctx->rec, sizeof(double) * NQ * ctx->batch, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t b = 0; b < ctx->batch; b++) record_to_events(ctx->hrec + b * NQ, out + b * MARL_NEVENTS);
+    return 0;
+}
+
+int marl_events(marl_ctx* ctx, const double* y, double* out)
+{
+    if (!ctx || !y || !out) return ctx ? fail(ctx, -1, "marl_events: invalid argument") : -1;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)NF * ctx->N * ctx->batch;
+    if (int rc = ensure(ctx, 0, n)) return rc;
+    HIP_OK(ctx, hipMemcpyAsync(ctx->buf[0], y, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    return marl_events_dev(ctx, ctx->buf[0], LAYOUT_FIELD_MAJOR, out);
+}
+
+int marl_convert_layout_dev(marl_ctx* ctx, const double* src_dev, double* dst_dev, int src_layout, int dst_layout)
+{
+    if (!ctx || !src_dev || !dst_dev || src_dev == dst_dev) return ctx ? fail(ctx, -1, "marl_convert_layout_dev: invalid argument") : -1;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    return launch_convert(ctx, src_dev, dst_dev, src_layout, dst_layout);
+}
+
+int marl_integrate_rk4_dev(marl_ctx* ctx, double* y_dev, int layout, double dt, int64_t nsteps)
+{
+    if (!ctx || !y_dev || nsteps < 0) return ctx ? fail(ctx, -1, "marl_integrate_rk4_dev: invalid argument") : -1;
+    if (ctx->batch != 1) return fail(ctx, -1, "marl_integrate_rk4_dev: single-instance context required (use marl_sweep_rk4_dev)");
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    if (int rc = ensure(ctx, 1, (size_t)state_doubles(ctx->slab.n_buf, layout))) return rc;
+    return rk4_run(ctx, y_dev, ctx->buf[1], layout, dt, nsteps);
+}
+
+int marl_sweep_rk4_dev(marl_ctx* ctx, double* y_dev, const double* dt, int64_t nsteps)
+{
+    if (!ctx || !y_dev || !dt || nsteps < 0) return ctx ? fail(ctx, -1, "marl_sweep_rk4_dev: invalid argument") : -1;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    const int v = default_sweep_variant(ctx);
+    if (v < 0) return fail(ctx, -1, "marl_sweep_rk4_dev: N = %lld exceeds the largest one-workgroup window (1024 cells)", (long long)ctx->N);
+    HIP_OK(ctx, hipMemcpyAsync(ctx->ddt, dt, sizeof(double) * ctx->batch, hipMemcpyHostToDevice, ctx->stream));
+    const dim3 grid((unsigned)ctx->batch);
+    SWEEP_DISPATCH(rk4_sweep_kernel, y_dev, ctx->dconsts, ctx->ddt, ctx->N, nsteps)
+    LAUNCH_OK(ctx);
+    return 0;
+}
+
+int marl_integrate_rk4(marl_ctx* ctx, double* y, double dt, int64_t nsteps)
+{
+    if (!ctx || !y || nsteps < 0) return ctx ? fail(ctx, -1, "marl_integrate_rk4: invalid argument") : -1;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)NF * ctx->N * ctx->batch;
+    if (int rc = ensure(ctx, 2, n)) return rc;
+    HIP_OK(ctx, hipMemcpyAsync(ctx->buf[2], y, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->batch > 1 || default_sweep_variant(ctx) >= 0) {
+        // small grids (one workgroup each, on-chip for all steps) and sweeps
+        std::vector<double> dts((size_t)ctx->batch, dt);
+        if (int rc = marl_sweep_rk4_dev(ctx, ctx->buf[2], dts.data(), nsteps)) return rc;
+    } else {
+        const int layout = (int)ctx->host_layout;
+        const size_t sd = (size_t)state_doubles(ctx->N, layout);
+        if (int rc = ensure(ctx, 0, sd)) return rc;
+        if (int rc = ensure(ctx, 1, sd)) return rc;
+        if (int rc = launch_convert(ctx, ctx->buf[2], ctx->buf[0], LAYOUT_FIELD_MAJOR, layout)) return rc;
+        if (int rc = rk4_run(ctx, ctx->buf[0], ctx->buf[1], layout, dt, nsteps)) return rc;
+        if (int rc = launch_convert(ctx, ctx->buf[0], ctx->buf[2], layout, LAYOUT_FIELD_MAJOR)) return rc;
+    }
+    HIP_OK(ctx, hipMemcpyAsync(y, ctx->buf[2], n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int marl_sweep_rk45_dev(marl_ctx* ctx, double* y_dev, double t0, double t1, double first_step, double rtol, double atol,
+                        int64_t max_attempts, marl_stats* stats)
+{
+    if (!ctx || !y_dev || !stats) return ctx ? fail(ctx, -1, "marl_sweep_rk45_dev: invalid argument") : -1;
+    if (!(first_step > 0) || !(t1 >= t0)) return fail(ctx, -1, "rk45: need first_step > 0 and t1 >= t0 (forward integration)");
+    if (t1 > t0 && first_step > t1 - t0) return fail(ctx, -1, "rk45: `first_step` exceeds bounds");
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    const int v = default_sweep_variant(ctx);
+    if (v < 0) return fail(ctx, -1, "marl_sweep_rk45_dev: N = %lld exceeds the largest one-workgroup window (1024 cells)", (long long)ctx->N);
+    if (int rc = launch_monitors(ctx, y_dev, LAYOUT_FIELD_MAJOR)) return rc;
+    hipLaunchKernelGGL(rk45_init_kernel, dim3((unsigned)ctx->batch), dim3(1), 0, ctx->stream, ctx->dctrl, ctx->rec, t0, t1, first_step, rtol,
+                       atol, (int64_t)NF * ctx->N, max_attempts, 0);
+    LAUNCH_OK(ctx);
+    const dim3 grid((unsigned)ctx->batch);
+    SWEEP_DISPATCH(rk45_sweep_kernel, y_dev, ctx->dconsts, ctx->dctrl, ctx->N, (double*)nullptr, (double*)nullptr)
+    LAUNCH_OK(ctx);
+    HIP_OK(ctx, hipMemcpyAsync(ctx->hctrl, ctx->dctrl, sizeof(Rk45Ctrl) * ctx->batch, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t b = 0; b < ctx->batch; b++) ctrl_to_stats(ctx->hctrl[b], &stats[b]);
+    return 0;
+}
+
+int marl_integrate_rk45_dev(marl_ctx* ctx, double* y_dev, int layout, double t0, double t1, double first_step, double rtol,
+                            double atol, int64_t max_attempts, marl_stats* stats)
+{
+    if (!ctx || !y_dev || !stats) return ctx ? fail(ctx, -1, "marl_integrate_rk45_dev: invalid argument") : -1;
+    if (ctx->batch != 1) return fail(ctx, -1, "marl_integrate_rk45_dev: single-instance context required (use marl_sweep_rk45_dev)");
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    const size_t sd = (size_t)state_doubles(ctx->slab.n_buf, layout);
+    for (int i = 0; i < 4; i++)
+        if (int rc = ensure(ctx, i, sd)) return rc;
+    HIP_OK(ctx, hipMemcpyAsync(ctx->buf[0], y_dev, sd * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    if (int rc = rk45_run(ctx, layout, false, t0, t1, first_step, rtol, atol, nullptr, 0, nullptr, nullptr, 0, max_attempts, stats)) return rc;
+    HIP_OK(ctx, hipMemcpyAsync(y_dev, ctx->buf[0], sd * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    return stats->status;
+}
+
+int marl_integrate_rk45(marl_ctx* ctx, double* y, double t0, double t1, double first_step, double rtol, double atol,
+                        const double* t_eval, int64_t n_eval, double* y_eval, double* t_events, int64_t max_events,
+                        int64_t max_attempts, marl_stats* stats)
+{
+    if (!ctx || !y || !stats || (n_eval > 0 && (!t_eval || !y_eval))) return ctx ? fail(ctx, -1, "marl_integrate_rk45: invalid argument") : -1;
+    if (ctx->batch != 1) return fail(ctx, -1, "marl_integrate_rk45: single-instance context required (use marl_sweep_rk45_dev)");
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    const bool small = default_sweep_variant(ctx) >= 0;
+    const int layout = small ? LAYOUT_FIELD_MAJOR : (int)ctx->host_layout;
+    const size_t n = (size_t)NF * ctx->N;
+    const size_t sd = (size_t)state_doubles(ctx->N, layout);
+    for (int i = 0; i < 4; i++)
+        if (int rc = ensure(ctx, i, sd > n ? sd : n)) return rc;
+    // upload field-major into buf[1], convert into buf[0]
+    HIP_OK(ctx, hipMemcpyAsync(ctx->buf[1], y, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = launch_convert(ctx, ctx->buf[1], ctx->buf[0], LAYOUT_FIELD_MAJOR, layout)) return rc;
+    double* yev = nullptr;
+    if (n_eval > 0) HIP_OK(ctx, hipMalloc((void**)&yev, sizeof(double) * sd * (size_t)(n_eval + 1)));
+    int rc = rk45_run(ctx, layout, small, t0, t1, first_step, rtol, atol, t_eval, n_eval, yev, t_events, max_events, max_attempts, stats);
+    if (rc == 0) {
+        // results back to field-major through a spare slot
+        for (int64_t i = 0; i < n_eval && rc == 0; i++) {
+            rc = launch_convert(ctx, yev + i * sd, yev + n_eval * sd, layout, LAYOUT_FIELD_MAJOR);
+            if (rc == 0 && hipMemcpyAsync(y_eval + i * n, yev + n_eval * sd, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+                rc = fail(ctx, -3, "copy of t_eval sample failed");
+            if (rc == 0 && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, -3, "sync failed");
+        }
+        if (rc == 0) rc = launch_convert(ctx, ctx->buf[0], ctx->buf[1], layout, LAYOUT_FIELD_MAJOR);
+        if (rc == 0 && hipMemcpyAsync(y, ctx->buf[1], n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+            rc = fail(ctx, -3, "copy of final state failed");
+        if (rc == 0 && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, -3, "sync failed");
+    }
+    if (yev) (void)hipFree(yev);
+    return rc ? rc : stats->status;
+}
+
+}  // extern "C"

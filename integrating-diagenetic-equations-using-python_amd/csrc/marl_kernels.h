@@ -1,0 +1,782 @@
+// marl_kernels.h - HIP kernels for the five-field RHS and the fused explicit RK time loops (gfx950).
+//
+// Work decomposition (all kernels): a workgroup of BLK threads owns a WINDOW of BLK*CPT
+// consecutive depth cells, CPT consecutive cells per thread, all five fields of a cell in that
+// thread's registers.  A Runge-Kutta stage needs u[i-1], u[i], u[i+1] of the current STAGE state:
+// cells inside a thread come from registers, the two thread-edge cells are exchanged through a
+// double-buffered LDS edge array (one barrier per stage).  Stage vectors K1..Ks never leave
+// registers.  A window is wider than the cells it finally writes by H cells per side; every RHS
+// evaluation invalidates one more cell at each window edge (the halo is recomputed, never
+// communicated), so one launch can advance several stages - a whole RK4 step, NSTEPS RK4 steps, or a
+// whole Dormand-Prince attempt - with ONE read and ONE write of the state: 80 algorithmic bytes per
+// grid-point-step.  Physical boundaries (global cell 0 / N-1) use the ghost-cell rules instead of
+// a halo and are therefore always valid.
+//
+// State layouts (`LAYOUT`):
+//   FIELD_MAJOR  y[f*ld + i]                         the reference's layout (Evolve_scenario.py:64-65)
+//   TILED        y[(i>>6)*320 + f*64 + (i&63)]       five 512-byte field rows interleaved per 64-cell
+//                                                    tile: one window = one contiguous 40*WIN-byte run
+#pragma once
+#include "marl_math.h"
+
+namespace marl {
+
+enum : int { LAYOUT_FIELD_MAJOR = 0, LAYOUT_TILED = 1 };
+
+template <int LAYOUT>
+__device__ __forceinline__ int64_t at(int f, int64_t i, int64_t ld)
+{
+    if constexpr (LAYOUT == LAYOUT_FIELD_MAJOR)
+        return (int64_t)f * ld + i;
+    else
+        return (i >> 6) * (int64_t)(NF * 64) + f * 64 + (i & 63);
+}
+
+// A contiguous piece of the global grid held in one buffer: local cell l is global cell l + goff.
+// Single-GPU runs: n_buf = N, goff = 0.  Domain decomposition: the buffer carries exchanged halo
+// cells on interior sides.
+struct Slab {
+    int64_t n_buf;   // cells in the buffer
+    int64_t goff;    // global index of local cell 0
+    int64_t ld;      // field stride of FIELD_MAJOR buffers (>= n_buf)
+    int64_t out_lo;  // local cells [out_lo, out_hi) are written by fused kernels
+    int64_t out_hi;
+};
+
+__device__ __forceinline__ double nanmin(double a, double b) { return (a < b || a != a) ? a : b; }
+__device__ __forceinline__ double nanmax(double a, double b) { return (a > b || a != a) ? a : b; }
+
+// ---------------------------------------------------------------------------------------------
+// Per-block stencil engine
+// ---------------------------------------------------------------------------------------------
+template <int BLK, int CPT>
+struct StencilBlock {
+    static constexpr int WIN = BLK * CPT;
+    static constexpr int NSIDE = (CPT == 1) ? 1 : 2;
+    static constexpr int LDS_DOUBLES = 2 * NSIDE * NF * BLK;  // [parity][side][field][thread]
+
+    double* lds;
+    int tid;
+    int parity;
+    int64_t g0;  // global index of this thread's first cell
+
+    __device__ __forceinline__ StencilBlock(double* lds_, int64_t g0_) : lds(lds_), tid(threadIdx.x), parity(0), g0(g0_) {}
+
+    // k[c] = RHS(stage state ys) for the thread's CPT cells.  Contains exactly one __syncthreads().
+    __device__ __forceinline__ void eval(const double (&ys)[CPT][NF], double (&k)[CPT][NF], PointAux (&aux)[CPT],
+                                         const DevConsts& C)
+    {
+        double* e = lds + parity * (NSIDE * NF * BLK);
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            e[f * BLK + tid] = ys[0][f];
+            if constexpr (CPT > 1) e[(NF + f) * BLK + tid] = ys[CPT - 1][f];
+        }
+        __syncthreads();
+        const int tl = tid > 0 ? tid - 1 : 0;
+        const int tr = tid < BLK - 1 ? tid + 1 : BLK - 1;
+        double left[NF], right[NF];
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            left[f] = e[((NSIDE - 1) * NF + f) * BLK + tl];  // left neighbour's LAST cell
+            right[f] = e[f * BLK + tr];                      // right neighbour's FIRST cell
+        }
+        parity ^= 1;
+#pragma unroll
+        for (int c = 0; c < CPT; c++) {
+            const int64_t g = g0 + c;
+            double um[NF], up[NF];
+#pragma unroll
+            for (int f = 0; f < NF; f++) {
+                um[f] = (c == 0) ? left[f] : ys[c > 0 ? c - 1 : 0][f];
+                up[f] = (c == CPT - 1) ? right[f] : ys[c < CPT - 1 ? c + 1 : c][f];
+            }
+            if (g == C.N - 1) {
+#pragma unroll
+                for (int f = 0; f < NF; f++) up[f] = ghost_upper(f, ys[c][f], um[f]);
+            }
+            if (g == 0) {
+#pragma unroll
+                for (int f = 0; f < NF; f++) um[f] = ghost_lower(C.bc[f], ys[c][f]);
+            }
+            rhs_point(ys[c], um, up, g >= C.mask_lo && g < C.mask_hi, C, k[c], aux[c]);
+        }
+    }
+};
+
+// Block-wide reduction of NQ quantities: q[0] summed, q[1..NMIN] min-reduced, the rest max-reduced.
+// Result valid in thread 0.  `scratch` holds NQ * (BLK/64) doubles.
+template <int BLK, int NQ, int NMIN>
+__device__ __forceinline__ void block_reduce(double (&q)[NQ], double* scratch)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int j = 0; j < NQ; j++) {
+            const double o = __shfl_xor(q[j], off, 64);
+            q[j] = (j == 0) ? q[j] + o : (j <= NMIN ? nanmin(q[j], o) : nanmax(q[j], o));
+        }
+    }
+    constexpr int NW = BLK / 64;
+    if constexpr (NW > 1) {
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < NQ; j++) scratch[j * NW + wave] = q[j];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int j = 0; j < NQ; j++) {
+                double a = scratch[j * NW];
+                for (int w = 1; w < NW; w++) {
+                    const double o = scratch[j * NW + w];
+                    a = (j == 0) ? a + o : (j <= NMIN ? nanmin(a, o) : nanmax(a, o));
+                }
+                q[j] = a;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stand-alone RHS: dydt = f(y).  The drop-in for the reference's fun / fun_numba callable
+// (marlpde/LHeureux_model.py:162, :290).  One thread per cell, neighbours straight from L1/L2.
+// ---------------------------------------------------------------------------------------------
+template <int LAYOUT>
+__global__ void __launch_bounds__(256) rhs_kernel(const double* __restrict__ y, double* __restrict__ dydt,
+                                                  const DevConsts* __restrict__ consts, Slab S, int64_t inst_stride)
+{
+    const DevConsts& C = consts[blockIdx.y];
+    y += blockIdx.y * inst_stride;
+    dydt += blockIdx.y * inst_stride;
+    const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (l < S.out_lo || l >= S.out_hi) return;
+    const int64_t g = l + S.goff;
+    double uc[NF], um[NF], up[NF], r[NF];
+    PointAux aux;
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+        uc[f] = y[at<LAYOUT>(f, l, S.ld)];
+        um[f] = (g > 0) ? y[at<LAYOUT>(f, l - 1, S.ld)] : ghost_lower(C.bc[f], uc[f]);
+    }
+#pragma unroll
+    for (int f = 0; f < NF; f++) up[f] = (g < C.N - 1) ? y[at<LAYOUT>(f, l + 1, S.ld)] : ghost_upper(f, uc[f], um[f]);
+    rhs_point(uc, um, up, g >= C.mask_lo && g < C.mask_hi, C, r, aux);
+#pragma unroll
+    for (int f = 0; f < NF; f++) dydt[at<LAYOUT>(f, l, S.ld)] = r[f];
+}
+
+// Layout conversion FIELD_MAJOR <-> TILED (entry / exit of the fused integrators only).
+template <int SRC, int DST>
+__global__ void __launch_bounds__(256) convert_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t n,
+                                                      int64_t ld_src, int64_t ld_dst, int64_t stride_src, int64_t stride_dst)
+{
+    src += blockIdx.y * stride_src;
+    dst += blockIdx.y * stride_dst;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int f = 0; f < NF; f++) dst[at<DST>(f, i, ld_dst)] = src[at<SRC>(f, i, ld_src)];
+}
+
+// ---------------------------------------------------------------------------------------------
+// The seven monitors (marlpde/LHeureux_model.py:524-593) as per-block partials:
+//   part[b][0] unused (sum slot), [1] min(y) [2] min CA [3] min CC [4] min U [5] max(CA+CC) [6] max Phi [7] max W
+// ---------------------------------------------------------------------------------------------
+constexpr int NQ = 8;    // reduction record: sum-of-squares + 7 monitor extrema
+constexpr int NQMIN = 4; // slots 1..4 are minima, 5..7 maxima
+
+__device__ __forceinline__ void monitors_init(double (&q)[NQ])
+{
+    q[0] = 0.0;
+    q[1] = q[2] = q[3] = q[4] = __builtin_inf();
+    q[5] = q[6] = q[7] = -__builtin_inf();
+}
+
+__device__ __forceinline__ void monitors_accumulate(double (&q)[NQ], const double (&u)[NF], double U, double W)
+{
+    q[1] = nanmin(nanmin(nanmin(nanmin(nanmin(q[1], u[0]), u[1]), u[2]), u[3]), u[4]);
+    q[2] = nanmin(q[2], u[0]);
+    q[3] = nanmin(q[3], u[1]);
+    q[4] = nanmin(q[4], U);
+    q[5] = nanmax(q[5], u[0] + u[1]);
+    q[6] = nanmax(q[6], u[4]);
+    q[7] = nanmax(q[7], W);
+}
+
+template <int LAYOUT>
+__global__ void __launch_bounds__(256) monitors_kernel(const double* __restrict__ y, const DevConsts* __restrict__ consts,
+                                                       Slab S, int64_t inst_stride, double* __restrict__ part)
+{
+    __shared__ double scratch[NQ * 4];
+    const DevConsts& C = consts[blockIdx.y];
+    y += blockIdx.y * inst_stride;
+    double q[NQ];
+    monitors_init(q);
+    for (int64_t l = S.out_lo + (int64_t)blockIdx.x * 256 + threadIdx.x; l < S.out_hi; l += (int64_t)gridDim.x * 256) {
+        double u[NF];
+#pragma unroll
+        for (int f = 0; f < NF; f++) u[f] = y[at<LAYOUT>(f, l, S.ld)];
+        const double Phi = u[4];
+        const double F = 1.0 - exp(10.0 - 10.0 * rcp_nr(Phi));
+        const double rF = C.rhorat * F;
+        monitors_accumulate(q, u, C.presum + rF * (Phi * Phi * Phi) * rcp_nr(1.0 - Phi), C.presum - rF * Phi * Phi);
+    }
+    block_reduce<256, NQ, NQMIN>(q, scratch);
+    if (threadIdx.x == 0) {
+        double* p = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NQ;
+#pragma unroll
+        for (int j = 0; j < NQ; j++) p[j] = q[j];
+    }
+}
+
+// Deterministic second-level reduction: `nblocks` records -> one record per instance.
+__global__ void __launch_bounds__(256) reduce_records_kernel(const double* __restrict__ part, int64_t nblocks, double* __restrict__ out)
+{
+    __shared__ double scratch[NQ * 4];
+    part += (int64_t)blockIdx.x * nblocks * NQ;
+    double q[NQ];
+    monitors_init(q);
+    for (int64_t b = threadIdx.x; b < nblocks; b += 256) {
+#pragma unroll
+        for (int j = 0; j < NQ; j++) {
+            const double o = part[b * NQ + j];
+            q[j] = (j == 0) ? q[j] + o : (j <= NQMIN ? nanmin(q[j], o) : nanmax(q[j], o));
+        }
+    }
+    block_reduce<256, NQ, NQMIN>(q, scratch);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < NQ; j++) out[(int64_t)blockIdx.x * NQ + j] = q[j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shared load / store of a thread's cells
+// ---------------------------------------------------------------------------------------------
+template <int CPT, int LAYOUT>
+__device__ __forceinline__ void load_cells(const double* __restrict__ y, int64_t l0, const Slab& S, const DevConsts& C,
+                                           double (&u)[CPT][NF])
+{
+#pragma unroll
+    for (int c = 0; c < CPT; c++) {
+        const int64_t l = l0 + c;
+        const bool in = l >= 0 && l < S.n_buf;
+#pragma unroll
+        for (int f = 0; f < NF; f++) u[c][f] = in ? y[at<LAYOUT>(f, l, S.ld)] : C.bc[f];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused classical RK4: NSTEPS whole steps per launch (BASELINE config 2 / headline).
+//   k1 = f(y); k2 = f(y + dt/2 k1); k3 = f(y + dt/2 k2); k4 = f(y + dt k3)
+//   y <- y + dt/6 (((k1 + 2 k2) + 2 k3) + k4)                 (same order as oracle/marl_oracle.c)
+// ---------------------------------------------------------------------------------------------
+template <int BLK, int CPT, int LAYOUT, int NSTEPS>
+__global__ void __launch_bounds__(BLK) rk4_fused_kernel(const double* __restrict__ yin, double* __restrict__ yout,
+                                                        const DevConsts* __restrict__ consts, Slab S, double dt)
+{
+    constexpr int H = 4 * NSTEPS;
+    constexpr int WIN = BLK * CPT;
+    constexpr int V = WIN - 2 * H;
+    static_assert(V > 0, "window too small for the fused halo");
+    __shared__ double lds[StencilBlock<BLK, CPT>::LDS_DOUBLES];
+    const DevConsts& C = consts[0];
+
+    const int64_t w0 = S.out_lo + (int64_t)blockIdx.x * V - H;  // window start, local index
+    const int64_t l0 = w0 + (int64_t)threadIdx.x * CPT;
+    StencilBlock<BLK, CPT> sb(lds, l0 + S.goff);
+
+    double y[CPT][NF], ys[CPT][NF], k[CPT][NF], acc[CPT][NF];
+    PointAux aux[CPT];
+    load_cells<CPT, LAYOUT>(yin, l0, S, C, y);
+    const double h2 = 0.5 * dt, h6 = dt / 6.0;
+
+#pragma unroll 1
+    for (int step = 0; step < NSTEPS; step++) {
+        sb.eval(y, k, aux, C);
+#pragma unroll
+        for (int c = 0; c < CPT; c++)
+#pragma unroll
+            for (int f = 0; f < NF; f++) { acc[c][f] = k[c][f]; ys[c][f] = y[c][f] + h2 * k[c][f]; }
+        sb.eval(ys, k, aux, C);
+#pragma unroll
+        for (int c = 0; c < CPT; c++)
+#pragma unroll
+            for (int f = 0; f < NF; f++) { acc[c][f] = acc[c][f] + 2.0 * k[c][f]; ys[c][f] = y[c][f] + h2 * k[c][f]; }
+        sb.eval(ys, k, aux, C);
+#pragma unroll
+        for (int c = 0; c < CPT; c++)
+#pragma unroll
+            for (int f = 0; f < NF; f++) { acc[c][f] = acc[c][f] + 2.0 * k[c][f]; ys[c][f] = y[c][f] + dt * k[c][f]; }
+        sb.eval(ys, k, aux, C);
+#pragma unroll
+        for (int c = 0; c < CPT; c++)
+#pragma unroll
+            for (int f = 0; f < NF; f++) y[c][f] = y[c][f] + h6 * (acc[c][f] + k[c][f]);
+    }
+
+#pragma unroll
+    for (int c = 0; c < CPT; c++) {
+        const int wi = threadIdx.x * CPT + c;
+        const int64_t l = l0 + c;
+        if (wi >= H && wi < WIN - H && l >= S.out_lo && l < S.out_hi) {
+#pragma unroll
+            for (int f = 0; f < NF; f++) yout[at<LAYOUT>(f, l, S.ld)] = y[c][f];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dormand-Prince 5(4) coefficients: scipy/integrate/_ivp/rk.py:377-391
+// ---------------------------------------------------------------------------------------------
+namespace dp {
+constexpr double A21 = 1.0 / 5;
+constexpr double A31 = 3.0 / 40, A32 = 9.0 / 40;
+constexpr double A41 = 44.0 / 45, A42 = -56.0 / 15, A43 = 32.0 / 9;
+constexpr double A51 = 19372.0 / 6561, A52 = -25360.0 / 2187, A53 = 64448.0 / 6561, A54 = -212.0 / 729;
+constexpr double A61 = 9017.0 / 3168, A62 = -355.0 / 33, A63 = 46732.0 / 5247, A64 = 49.0 / 176, A65 = -5103.0 / 18656;
+constexpr double B1 = 35.0 / 384, B3 = 500.0 / 1113, B4 = 125.0 / 192, B5 = -2187.0 / 6784, B6 = 11.0 / 84;
+constexpr double E1 = -71.0 / 57600, E3 = 71.0 / 16695, E4 = -71.0 / 1920, E5 = 17253.0 / 339200, E6 = -22.0 / 525, E7 = 1.0 / 40;
+constexpr double SAFETY = 0.9, MIN_FACTOR = 0.2, MAX_FACTOR = 10.0;
+}  // namespace dp
+
+
+enum : int { ST_DONE = 0, ST_RUNNING = 1, ST_BUDGET = 2, ST_PAUSED = 3, ST_TOO_SMALL = -1 };
+
+// Device-resident step controller: the scalar state of scipy's RungeKutta._step_impl
+// (rk.py:111-176) plus the driver's event bookkeeping (ivp.py:673-694).  One per instance.
+// Plain data; mirrored field for field by the ctypes structure in _abi.py.
+struct Rk45Ctrl {
+    double t, h_abs, t_bound, rtol, atol;
+    double h_try, t_new;     // the attempt in flight (h_try = t_new - t, clipped at t_bound)
+    double t_old, h_prev;    // last accepted step [t_old, t_old + h_prev] (dense output)
+    double err_norm;         // error norm of the last attempt
+    double pause_t;          // pause (ST_PAUSED) after the accepted step that reaches this time; +inf = never
+    double g[7];             // monitors at the last accepted state (ivp.py:645, :694)
+    double ev_first[7];      // first / latest sign change per monitor, located by linear interpolation
+    double ev_last[7];       //   inside the bracketing step (the host refines with dense output + Brent)
+    int64_t n_events[7];
+    int64_t nfev, n_acc, n_rej, attempts, max_attempts;
+    int64_t n_total;         // 5 * N of the global grid: size of the RMS norm (common.py:63-65)
+    int32_t status;          // ST_*
+    int32_t cur;             // which of the two state / FSAL buffers holds (y, f) at time t
+    int32_t rejected;        // a rejection happened in the step in progress (rk.py:128,163-165)
+    int32_t accepted_last;   // the last attempt was accepted
+    int32_t pause_on_event;  // pause after an accepted step in which a monitor changed sign
+    int32_t event_fired;     // set with ST_PAUSED when that was the reason
+};
+
+// Top of RungeKutta._step_impl: choose the step of the next attempt (rk.py:119-142).
+__device__ __forceinline__ void rk45_prepare_attempt(Rk45Ctrl& c)
+{
+    const double min_step = 10.0 * fabs(nextafter(c.t, __builtin_inf()) - c.t);
+    if (!c.rejected) {
+        if (c.h_abs < min_step) c.h_abs = min_step;
+    } else if (c.h_abs < min_step) {
+        c.status = ST_TOO_SMALL;
+        return;
+    }
+    if (c.max_attempts > 0 && c.attempts >= c.max_attempts) {
+        c.status = ST_BUDGET;
+        return;
+    }
+    double t_new = c.t + c.h_abs;
+    if (t_new - c.t_bound > 0.0) t_new = c.t_bound;
+    c.t_new = t_new;
+    c.h_try = t_new - c.t;
+    c.h_abs = fabs(c.h_try);
+    c.attempts++;
+}
+
+// Bottom of _step_impl + the driver's per-step bookkeeping.  rec = {sum (err/scale)^2, monitors of y_new}.
+__device__ __forceinline__ void rk45_finish_attempt(Rk45Ctrl& c, const double (&rec)[NQ])
+{
+    const double err = sqrt(rec[0]) / sqrt((double)c.n_total);  // common.py:63-65
+    c.err_norm = err;
+    c.nfev += 6;
+    const double f = dp::SAFETY * pow(err, -0.2);
+    if (err < 1.0) {  // rk.py:149-161
+        double factor = (err == 0.0) ? dp::MAX_FACTOR : ((f < dp::MAX_FACTOR) ? f : dp::MAX_FACTOR);
+        if (c.rejected && !(factor < 1.0)) factor = 1.0;
+        c.h_abs *= factor;
+        c.accepted_last = 1;
+        c.rejected = 0;
+        c.n_acc++;
+        c.t_old = c.t;
+        c.h_prev = c.h_try;
+        c.t = c.t_new;
+        c.cur ^= 1;
+        // monitors, in the reference's order (Evolve_scenario.py:107-109)
+        const double gn[7] = {rec[1], rec[2], rec[3], rec[5] - 1.0, rec[6] - 1.0, rec[4], rec[7]};
+        int fired = 0;
+#pragma unroll
+        for (int e = 0; e < 7; e++) {
+            const double go = c.g[e];
+            const bool up = go <= 0.0 && gn[e] >= 0.0, down = go >= 0.0 && gn[e] <= 0.0;  // ivp.py:149-151
+            if (up || down) {
+                const double d = go - gn[e];
+                const double tc = (d != 0.0) ? c.t_old + c.h_prev * (go / d) : c.t;
+                if (c.n_events[e] == 0) c.ev_first[e] = tc;
+                c.ev_last[e] = tc;
+                c.n_events[e]++;
+                fired = 1;
+            }
+            c.g[e] = gn[e];
+        }
+        if (c.t - c.t_bound >= 0.0) {  // base.py:203-204
+            c.status = ST_DONE;
+        } else if (c.t >= c.pause_t || (fired && c.pause_on_event)) {
+            c.status = ST_PAUSED;
+            c.event_fired = fired;
+        }
+    } else {  // rk.py:162-165; a NaN norm lands here with factor 0.2
+        c.h_abs *= (f > dp::MIN_FACTOR) ? f : dp::MIN_FACTOR;
+        c.accepted_last = 0;
+        c.rejected = 1;
+        c.n_rej++;
+    }
+    if (c.status == ST_RUNNING) rk45_prepare_attempt(c);
+}
+
+// rec0: monitors record of y(t0).  RungeKutta.__init__ (rk.py:94-102) + ivp.py:645.
+__global__ void rk45_init_kernel(Rk45Ctrl* ctrl, const double* __restrict__ rec0, double t0, double t1, double first_step,
+                                 double rtol, double atol, int64_t n_total, int64_t max_attempts, int32_t cur)
+{
+    Rk45Ctrl c = {};
+    c.t = t0; c.t_bound = t1; c.h_abs = first_step; c.rtol = rtol; c.atol = atol;
+    c.t_old = t0; c.pause_t = __builtin_inf();
+    c.n_total = n_total; c.max_attempts = max_attempts; c.cur = cur;
+    c.nfev = 1;
+    c.status = (t0 == t1) ? ST_DONE : ST_RUNNING;  // base.py:189-194
+    const double* r = rec0 + (int64_t)blockIdx.x * NQ;
+    const double g0[7] = {r[1], r[2], r[3], r[5] - 1.0, r[6] - 1.0, r[4], r[7]};
+    for (int e = 0; e < 7; e++) c.g[e] = g0[e];
+    if (c.status == ST_RUNNING) rk45_prepare_attempt(c);
+    ctrl[blockIdx.x] = c;
+}
+
+// Resume a paused / budget-stopped controller (host sets new pause_t / max_attempts first).
+__global__ void rk45_resume_kernel(Rk45Ctrl* ctrl, double pause_t, int64_t max_attempts)
+{
+    Rk45Ctrl& c = ctrl[blockIdx.x];
+    c.pause_t = pause_t;
+    c.max_attempts = max_attempts;
+    if (c.status == ST_PAUSED || c.status == ST_BUDGET) {
+        c.status = ST_RUNNING;
+        c.event_fired = 0;
+        rk45_prepare_attempt(c);
+    }
+}
+
+// Combine `nrec` reduction records (per-block partials on one GPU, or one record per rank after the
+// all-gather of a domain-decomposed run) in index order and finish the attempt.
+__global__ void __launch_bounds__(256) rk45_control_kernel(const double* __restrict__ recs, int64_t nrec, Rk45Ctrl* ctrl)
+{
+    __shared__ double scratch[NQ * 4];
+    if (ctrl->status != ST_RUNNING) return;
+    double q[NQ];
+    monitors_init(q);
+    for (int64_t b = threadIdx.x; b < nrec; b += 256) {
+#pragma unroll
+        for (int j = 0; j < NQ; j++) {
+            const double o = recs[b * NQ + j];
+            q[j] = (j == 0) ? q[j] + o : (j <= NQMIN ? nanmin(q[j], o) : nanmax(q[j], o));
+        }
+    }
+    block_reduce<256, NQ, NQMIN>(q, scratch);
+    if (threadIdx.x == 0) {
+        Rk45Ctrl c = *ctrl;
+        rk45_finish_attempt(c, q);
+        *ctrl = c;
+    }
+}
+
+// One Dormand-Prince attempt on the per-thread cells: k1 given; returns y_new in `yn`, f(y_new) in `k7`
+// and the error-estimate numerator  sum_j E_j K_j  in `esum` (rk_step, rk.py:61-69; _estimate_error :103-104).
+// With DENSE, `esum` instead receives  sum_j w_j K_j  for the dense-output weights w_j = sum_m P[j][m] x^(m+1)
+// (RkDenseOutput, rk.py:560-574; w_2 = 0 because row 2 of P is zero).
+struct DenseWeights { double w[7]; };
+
+template <int BLK, int CPT, bool DENSE = false>
+__device__ __forceinline__ void dp45_attempt(StencilBlock<BLK, CPT>& sb, const DevConsts& C, double h,
+                                             const double (&y)[CPT][NF], const double (&k1)[CPT][NF],
+                                             double (&yn)[CPT][NF], double (&k7)[CPT][NF], double (&esum)[CPT][NF],
+                                             PointAux (&aux)[CPT], const DenseWeights& dw = DenseWeights{})
+{
+    const double e1 = DENSE ? dw.w[0] : dp::E1, e3 = DENSE ? dw.w[2] : dp::E3, e4 = DENSE ? dw.w[3] : dp::E4;
+    const double e5 = DENSE ? dw.w[4] : dp::E5, e6 = DENSE ? dw.w[5] : dp::E6, e7 = DENSE ? dw.w[6] : dp::E7;
+    double ys[CPT][NF], k2[CPT][NF], k3[CPT][NF], k4[CPT][NF], k5[CPT][NF], k6[CPT][NF];
+#define MARL_CELLS _Pragma("unroll") for (int c = 0; c < CPT; c++) _Pragma("unroll") for (int f = 0; f < NF; f++)
+    MARL_CELLS ys[c][f] = y[c][f] + (k1[c][f] * dp::A21) * h;
+    sb.eval(ys, k2, aux, C);
+    MARL_CELLS ys[c][f] = y[c][f] + (k1[c][f] * dp::A31 + k2[c][f] * dp::A32) * h;
+    sb.eval(ys, k3, aux, C);
+    MARL_CELLS ys[c][f] = y[c][f] + (k1[c][f] * dp::A41 + k2[c][f] * dp::A42 + k3[c][f] * dp::A43) * h;
+    sb.eval(ys, k4, aux, C);
+    MARL_CELLS ys[c][f] = y[c][f] + (k1[c][f] * dp::A51 + k2[c][f] * dp::A52 + k3[c][f] * dp::A53 + k4[c][f] * dp::A54) * h;
+    sb.eval(ys, k5, aux, C);
+    MARL_CELLS ys[c][f] = y[c][f] + (k1[c][f] * dp::A61 + k2[c][f] * dp::A62 + k3[c][f] * dp::A63 + k4[c][f] * dp::A64 + k5[c][f] * dp::A65) * h;
+    sb.eval(ys, k6, aux, C);
+    MARL_CELLS {
+        yn[c][f] = y[c][f] + h * (k1[c][f] * dp::B1 + k3[c][f] * dp::B3 + k4[c][f] * dp::B4 + k5[c][f] * dp::B5 + k6[c][f] * dp::B6);
+        esum[c][f] = k1[c][f] * e1 + k3[c][f] * e3 + k4[c][f] * e4 + k5[c][f] * e5 + k6[c][f] * e6;
+    }
+    sb.eval(yn, k7, aux, C);
+    MARL_CELLS esum[c][f] = esum[c][f] + k7[c][f] * e7;
+#undef MARL_CELLS
+}
+
+// (err/scale)^2 of one component; scale = atol + max(|y|, |y_new|) * rtol  (rk.py:146-147)
+__device__ __forceinline__ double dp45_err2(double esum, double h, double y, double yn, double rtol, double atol)
+{
+    const double ay = fabs(y), an = fabs(yn);
+    const double scale = atol + ((ay > an || ay != ay) ? ay : an) * rtol;
+    const double e = esum * h * rcp_nr(scale);
+    return e * e;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused adaptive attempt for ONE large grid (or one slab of a domain-decomposed grid): reads
+// (y, f) from buffer `cur`, writes (y_new, f_new) into the other buffer and one reduction record per
+// block; rk45_control_kernel then accepts (flips `cur`) or rejects.  FSAL: f_new becomes K1.
+// ---------------------------------------------------------------------------------------------
+template <int BLK, int CPT, int LAYOUT>
+__global__ void __launch_bounds__(BLK) rk45_attempt_kernel(double* __restrict__ Y0, double* __restrict__ Y1,
+                                                           double* __restrict__ F0, double* __restrict__ F1,
+                                                           const DevConsts* __restrict__ consts, Slab S,
+                                                           const Rk45Ctrl* __restrict__ ctrl, double* __restrict__ part)
+{
+    constexpr int H = 6;
+    constexpr int WIN = BLK * CPT;
+    constexpr int V = WIN - 2 * H;
+    __shared__ double lds[StencilBlock<BLK, CPT>::LDS_DOUBLES + NQ * (BLK / 64)];
+    if (ctrl->status != ST_RUNNING) return;
+    const DevConsts& C = consts[0];
+    const int cur = ctrl->cur;
+    const double h = ctrl->h_try, rtol = ctrl->rtol, atol = ctrl->atol;
+    const double* yin = cur ? Y1 : Y0;
+    const double* fin = cur ? F1 : F0;
+    double* yout = cur ? Y0 : Y1;
+    double* fout = cur ? F0 : F1;
+
+    const int64_t w0 = S.out_lo + (int64_t)blockIdx.x * V - H;
+    const int64_t l0 = w0 + (int64_t)threadIdx.x * CPT;
+    StencilBlock<BLK, CPT> sb(lds, l0 + S.goff);
+
+    double y[CPT][NF], k1[CPT][NF], yn[CPT][NF], k7[CPT][NF], esum[CPT][NF];
+    PointAux aux[CPT];
+    load_cells<CPT, LAYOUT>(yin, l0, S, C, y);
+#pragma unroll
+    for (int c = 0; c < CPT; c++) {
+        const int64_t l = l0 + c;
+        const bool in = l >= 0 && l < S.n_buf;
+#pragma unroll
+        for (int f = 0; f < NF; f++) k1[c][f] = in ? fin[at<LAYOUT>(f, l, S.ld)] : 0.0;
+    }
+    dp45_attempt<BLK, CPT>(sb, C, h, y, k1, yn, k7, esum, aux);
+
+    double q[NQ];
+    monitors_init(q);
+#pragma unroll
+    for (int c = 0; c < CPT; c++) {
+        const int wi = threadIdx.x * CPT + c;
+        const int64_t l = l0 + c;
+        if (wi >= H && wi < WIN - H && l >= S.out_lo && l < S.out_hi) {
+#pragma unroll
+            for (int f = 0; f < NF; f++) {
+                yout[at<LAYOUT>(f, l, S.ld)] = yn[c][f];
+                fout[at<LAYOUT>(f, l, S.ld)] = k7[c][f];
+                q[0] += dp45_err2(esum[c][f], h, y[c][f], yn[c][f], rtol, atol);
+            }
+            monitors_accumulate(q, yn[c], aux[c].U, aux[c].W);
+        }
+    }
+    block_reduce<BLK, NQ, NQMIN>(q, lds + StencilBlock<BLK, CPT>::LDS_DOUBLES);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < NQ; j++) part[(int64_t)blockIdx.x * NQ + j] = q[j];
+    }
+}
+
+// U and W of a state (monitors zeros_U / zeros_W, LHeureux_model.py:567-593)
+__device__ __forceinline__ void uw_point(double Phi, const DevConsts& C, double& U, double& W)
+{
+    const double F = 1.0 - exp(10.0 - 10.0 * rcp_nr(Phi));
+    const double rF = C.rhorat * F;
+    U = C.presum + rF * (Phi * Phi * Phi) * rcp_nr(1.0 - Phi);
+    W = C.presum - rF * Phi * Phi;
+}
+
+// Dense output of the step that starts at (yold, fold) with size h: replays the step's stages and
+// writes  y(t_old + x h) = y_old + h sum_j w_j(x) K_j  (t_eval samples, ivp.py:706-723) and/or the
+// monitors record of that state (event root finding, ivp.py:51-76).  yout may be NULL.
+template <int BLK, int CPT, int LAYOUT>
+__global__ void __launch_bounds__(BLK) rk45_dense_kernel(const double* __restrict__ yold, const double* __restrict__ fold,
+                                                         const DevConsts* __restrict__ consts, Slab S, double h,
+                                                         DenseWeights dw, double* __restrict__ yout, double* __restrict__ part)
+{
+    constexpr int H = 6;
+    constexpr int WIN = BLK * CPT;
+    constexpr int V = WIN - 2 * H;
+    __shared__ double lds[StencilBlock<BLK, CPT>::LDS_DOUBLES + NQ * (BLK / 64)];
+    const DevConsts& C = consts[0];
+    const int64_t w0 = S.out_lo + (int64_t)blockIdx.x * V - H;
+    const int64_t l0 = w0 + (int64_t)threadIdx.x * CPT;
+    StencilBlock<BLK, CPT> sb(lds, l0 + S.goff);
+    double y[CPT][NF], k1[CPT][NF], yn[CPT][NF], k7[CPT][NF], dsum[CPT][NF];
+    PointAux aux[CPT];
+    load_cells<CPT, LAYOUT>(yold, l0, S, C, y);
+#pragma unroll
+    for (int c = 0; c < CPT; c++) {
+        const int64_t l = l0 + c;
+        const bool in = l >= 0 && l < S.n_buf;
+#pragma unroll
+        for (int f = 0; f < NF; f++) k1[c][f] = in ? fold[at<LAYOUT>(f, l, S.ld)] : 0.0;
+    }
+    dp45_attempt<BLK, CPT, true>(sb, C, h, y, k1, yn, k7, dsum, aux, dw);
+    double q[NQ];
+    monitors_init(q);
+#pragma unroll
+    for (int c = 0; c < CPT; c++) {
+        const int wi = threadIdx.x * CPT + c;
+        const int64_t l = l0 + c;
+        if (wi >= H && wi < WIN - H && l >= S.out_lo && l < S.out_hi) {
+            double d[NF];
+#pragma unroll
+            for (int f = 0; f < NF; f++) {
+                d[f] = h * dsum[c][f] + y[c][f];
+                if (yout) yout[at<LAYOUT>(f, l, S.ld)] = d[f];
+            }
+            double U, W;
+            uw_point(d[4], C, U, W);
+            monitors_accumulate(q, d, U, W);
+        }
+    }
+    block_reduce<BLK, NQ, NQMIN>(q, lds + StencilBlock<BLK, CPT>::LDS_DOUBLES);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < NQ; j++) part[(int64_t)blockIdx.x * NQ + j] = q[j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batched parameter sweep (BASELINE configs 3-4): ONE workgroup integrates ONE instance
+// (N <= BLK*CPT cells) for all its steps.  State, stage vectors and the step controller stay
+// on-chip for the whole integration; global memory is touched at entry and exit only.
+//   Y: [batch][5][N] field-major per instance (the reference's layout, one instance after another).
+// ---------------------------------------------------------------------------------------------
+template <int BLK, int CPT>
+__global__ void __launch_bounds__(BLK) rk45_sweep_kernel(double* __restrict__ Y, const DevConsts* __restrict__ consts,
+                                                         Rk45Ctrl* __restrict__ ctrls, int64_t N,
+                                                         double* __restrict__ Yold, double* __restrict__ Fold)
+{
+    __shared__ double lds[StencilBlock<BLK, CPT>::LDS_DOUBLES + NQ * (BLK / 64)];
+    __shared__ Rk45Ctrl sc;
+    const DevConsts& C = consts[blockIdx.x];
+    double* yg = Y + (int64_t)blockIdx.x * NF * N;
+    Slab S = {N, 0, N, 0, N};
+    const int64_t l0 = (int64_t)threadIdx.x * CPT;
+    StencilBlock<BLK, CPT> sb(lds, l0);
+    if (threadIdx.x == 0) sc = ctrls[blockIdx.x];
+    __syncthreads();
+    if (sc.status != ST_RUNNING) return;
+    const double rtol = sc.rtol, atol = sc.atol;
+
+    double y[CPT][NF], k1[CPT][NF], yn[CPT][NF], k7[CPT][NF], esum[CPT][NF];
+    PointAux aux[CPT];
+    load_cells<CPT, LAYOUT_FIELD_MAJOR>(yg, l0, S, C, y);
+    sb.eval(y, k1, aux, C);  // f(t, y): RungeKutta.__init__ (first launch) or re-derived on resume
+
+    while (true) {
+        const double h = sc.h_try;
+        dp45_attempt<BLK, CPT>(sb, C, h, y, k1, yn, k7, esum, aux);
+        double q[NQ];
+        monitors_init(q);
+#pragma unroll
+        for (int c = 0; c < CPT; c++) {
+            if (l0 + c < N) {
+#pragma unroll
+                for (int f = 0; f < NF; f++) q[0] += dp45_err2(esum[c][f], h, y[c][f], yn[c][f], rtol, atol);
+                monitors_accumulate(q, yn[c], aux[c].U, aux[c].W);
+            }
+        }
+        block_reduce<BLK, NQ, NQMIN>(q, lds + StencilBlock<BLK, CPT>::LDS_DOUBLES);
+        if (threadIdx.x == 0) rk45_finish_attempt(sc, q);
+        __syncthreads();
+        const int status = sc.status;
+        if (sc.accepted_last) {
+            if (status != ST_RUNNING && Yold) {
+                // keep (y_old, f_old) of the step just accepted: the host replays it for dense output
+#pragma unroll
+                for (int c = 0; c < CPT; c++) {
+                    if (l0 + c < N) {
+#pragma unroll
+                        for (int f = 0; f < NF; f++) {
+                            Yold[(int64_t)blockIdx.x * NF * N + at<LAYOUT_FIELD_MAJOR>(f, l0 + c, N)] = y[c][f];
+                            Fold[(int64_t)blockIdx.x * NF * N + at<LAYOUT_FIELD_MAJOR>(f, l0 + c, N)] = k1[c][f];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CPT; c++)
+#pragma unroll
+                for (int f = 0; f < NF; f++) { y[c][f] = yn[c][f]; k1[c][f] = k7[c][f]; }
+        }
+        __syncthreads();  // everyone has read sc before thread 0 may touch it again
+        if (status != ST_RUNNING) break;
+    }
+#pragma unroll
+    for (int c = 0; c < CPT; c++) {
+        if (l0 + c < N) {
+#pragma unroll
+            for (int f = 0; f < NF; f++) yg[at<LAYOUT_FIELD_MAJOR>(f, l0 + c, N)] = y[c][f];
+        }
+    }
+    if (threadIdx.x == 0) {
+        sc.cur = 0;
+        ctrls[blockIdx.x] = sc;
+    }
+}
+
+template <int BLK, int CPT>
+__global__ void __launch_bounds__(BLK) rk4_sweep_kernel(double* __restrict__ Y, const DevConsts* __restrict__ consts,
+                                                        const double* __restrict__ dts, int64_t N, int64_t nsteps)
+{
+    __shared__ double lds[StencilBlock<BLK, CPT>::LDS_DOUBLES];
+    const DevConsts& C = consts[blockIdx.x];
+    double* yg = Y + (int64_t)blockIdx.x * NF * N;
+    Slab S = {N, 0, N, 0, N};
+    const int64_t l0 = (int64_t)threadIdx.x * CPT;
+    StencilBlock<BLK, CPT> sb(lds, l0);
+    const double dt = dts[blockIdx.x];
+    const double h2 = 0.5 * dt, h6 = dt / 6.0;
+    double y[CPT][NF], ys[CPT][NF], k[CPT][NF], acc[CPT][NF];
+    PointAux aux[CPT];
+    load_cells<CPT, LAYOUT_FIELD_MAJOR>(yg, l0, S, C, y);
+#define MARL_CELLS _Pragma("unroll") for (int c = 0; c < CPT; c++) _Pragma("unroll") for (int f = 0; f < NF; f++)
+#pragma unroll 1
+    for (int64_t s = 0; s < nsteps; s++) {
+        sb.eval(y, k, aux, C);
+        MARL_CELLS { acc[c][f] = k[c][f]; ys[c][f] = y[c][f] + h2 * k[c][f]; }
+        sb.eval(ys, k, aux, C);
+        MARL_CELLS { acc[c][f] = acc[c][f] + 2.0 * k[c][f]; ys[c][f] = y[c][f] + h2 * k[c][f]; }
+        sb.eval(ys, k, aux, C);
+        MARL_CELLS { acc[c][f] = acc[c][f] + 2.0 * k[c][f]; ys[c][f] = y[c][f] + dt * k[c][f]; }
+        sb.eval(ys, k, aux, C);
+        MARL_CELLS y[c][f] = y[c][f] + h6 * (acc[c][f] + k[c][f]);
+    }
+#undef MARL_CELLS
+#pragma unroll
+    for (int c = 0; c < CPT; c++) {
+        if (l0 + c < N) {
+#pragma unroll
+            for (int f = 0; f < NF; f++) yg[at<LAYOUT_FIELD_MAJOR>(f, l0 + c, N)] = y[c][f];
+        }
+    }
+}
+
+}  // namespace marl

@@ -1,0 +1,498 @@
+/* marl_oracle.c - CPU restatement of the reference's five-field RHS and explicit RK time loops.
+ *
+ * TEST INFRASTRUCTURE.  This file is the parity oracle and the "port" CPU baseline.  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the product
+ * path (libmarl_hip.so) never links, loads or calls anything in oracle/.
+ *
+ * Pinning: checked against tests/golden/ (vectors produced by the reference's own code, see
+ * oracle/make_goldens.py) and against the reference's three HDF5 regression goldens
+ * (tests/test_oracle_*.py).  The py-pde stencil/ghost-cell layer and the scipy controller are
+ * third-party code that is not under /root/reference; their published algorithms are
+ * restated here (py-pde 0.32.2, scipy 1.11.2 pinned by the reference's poetry.lock).
+ *
+ * Every function cites the reference lines it follows.  Arithmetic is written in the same
+ * operation order as the reference loop so that differences stay at the libm level.
+ * Compile with -ffp-contract=off (see oracle/Makefile).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/marl_params.h"
+
+#define NF MARL_NFIELDS
+
+/* ------------------------------------------------------------------------------------------
+ * Derived constants.  marlpde/LHeureux_model.py:23-24 (delta_x), :36-72, :87-88, :130-133.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    double dx;       /* grid.discretization = length / N: used by the stencils (py-pde) */
+    double delta_x;  /* x[1] - x[0] of the cell centres: used by the Peclet numbers (:23-24) */
+    double nu1, nu2, KRat, dCa, dCO3, delta, Da, lambda_, auxcon, rhorat0, rhorat, presum;
+    double F_fixed, dPhi_fixed, Peclet_min, Peclet_max;
+} orc_consts;
+
+static void orc_derive(const marl_params *p, int64_t N, orc_consts *c)
+{
+    const double g = 100 * 9.81;                                              /* :59 */
+    c->dx = p->length / (double)N;
+    c->delta_x = (0.0 + 1.5 * c->dx) - (0.0 + 0.5 * c->dx);                    /* :23-24 */
+    c->nu1 = p->k1 / p->k2;                                                    /* :36 */
+    c->nu2 = p->k4 / p->k3;                                                    /* :39 */
+    c->KRat = p->KC / p->KA;                                                   /* :51 */
+    c->dCa = p->DCa / p->D0Ca;                                                 /* :60 */
+    c->dCO3 = p->DCO3 / p->D0Ca;                                               /* :61 */
+    c->delta = p->rhos / (p->muA * sqrt(p->KC));                               /* :62 */
+    c->Da = p->k2 * p->Tstar;                                                  /* :63 */
+    c->lambda_ = p->k3 / p->k2;                                                /* :64 */
+    c->auxcon = p->beta / (p->D0Ca * p->b * g * p->rhow * (p->PhiNR - p->PhiInfty)); /* :65-66 */
+    c->rhorat0 = (p->rhos0 / p->rhow - 1) * p->beta / p->sedimentationrate;    /* :67-68 */
+    c->rhorat = (p->rhos / p->rhow - 1) * p->beta / p->sedimentationrate;      /* :69-70 */
+    c->presum = 1 - c->rhorat0 * pow(p->Phi0, 3) * (1 - exp(10 - 10 / p->Phi0)) / (1 - p->Phi0); /* :71-72 */
+    c->Peclet_min = 1e-2;                                                      /* :87 */
+    c->Peclet_max = 1 / c->Peclet_min;                                         /* :88 */
+    c->F_fixed = 1 - exp(10 - 10 / p->PhiIni);                                 /* :131 */
+    c->dPhi_fixed = c->auxcon * c->F_fixed * pow(p->PhiIni, 3) / (1 - p->PhiIni); /* :132-133 */
+}
+
+/* Exported so tests can compare the derived constants with tests/golden/derived_constants.json. */
+void marl_oracle_derive(const marl_params *p, int64_t N, double out[17])
+{
+    orc_consts c;
+    orc_derive(p, N, &c);
+    const double v[17] = {c.delta_x, c.nu1, c.nu2, c.KRat, c.dCa, c.dCO3, c.delta, c.Da, c.lambda_, c.auxcon,
+                          c.rhorat0, c.rhorat, c.presum, c.F_fixed, c.dPhi_fixed, c.Peclet_min, c.Peclet_max};
+    memcpy(out, v, sizeof v);
+}
+
+/* Depth mask not_too_shallow * not_too_deep, marlpde/Evolve_scenario.py:51-54: Heaviside with
+ * H(0) = 0 evaluated at the cell centres (i + 1/2) dx. */
+static inline double orc_mask(const marl_params *p, double dx, int64_t i)
+{
+    const double x = 0.0 + ((double)i + 0.5) * dx;
+    const double shallow = (x - p->shallow_limit) > 0 ? 1.0 : 0.0;
+    const double deep = (p->deep_limit - x) > 0 ? 1.0 : 0.0;
+    return deep * shallow;
+}
+
+/* Fiadeiro-Veronis weight, marlpde/LHeureux_model.py:437-442 (= calculate_sigma :147-160). */
+static inline double orc_sigma(double Pe, double W, double Pe_min, double Pe_max)
+{
+    if (fabs(Pe) < Pe_min) return 0.0;
+    if (fabs(Pe) > Pe_max) return (W > 0) - (W < 0) + (W != W ? W : 0.0); /* np.sign, NaN -> NaN */
+    return cosh(Pe) / sinh(Pe) - 1 / Pe;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * The RHS.  marlpde/LHeureux_model.py:361-522 (pde_rhs); ghost cells / stencils: py-pde
+ * semantics, SURVEY.md App. B (call sites LHeureux_model.py:26-30, 96-111, 372-384).
+ *   y, rate: field-major float64[5N] (Evolve_scenario.py:64-65).
+ * ---------------------------------------------------------------------------------------- */
+static void orc_rhs(const marl_params *p, const orc_consts *c, int64_t N, const double *y, double *rate)
+{
+    const double *CA = y, *CC = y + N, *cCa = y + 2 * N, *cCO3 = y + 3 * N, *Phi = y + 4 * N;
+    const double dx = c->dx;
+    const double lap_scale = pow(dx, -2);
+    const double bc0[NF] = {p->CA0, p->CC0, p->cCa0, p->cCO30, p->Phi0};
+    const double *fld[NF] = {CA, CC, cCa, cCO3, Phi};
+
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t i = 0; i < N; i++) {
+        /* neighbours incl. the two virtual cells: lower {"value": v} -> 2v - u[0];
+         * upper {"curvature": 0} (CA, CC) -> 2u[N-1] - u[N-2]; upper {"derivative": 0} -> u[N-1] */
+        double um[NF], up[NF];
+        for (int f = 0; f < NF; f++) {
+            um[f] = (i > 0) ? fld[f][i - 1] : 2.0 * bc0[f] - fld[f][0];
+            if (i < N - 1)
+                up[f] = fld[f][i + 1];
+            else if (f < 2)
+                up[f] = 0.0 * dx * dx + 2.0 * fld[f][N - 1] - fld[f][N - 2];
+            else
+                up[f] = fld[f][N - 1] + dx * 0.0;
+        }
+        /* :372-384 */
+        const double CA_grad_back = (CA[i] - um[0]) / dx, CA_grad_forw = (up[0] - CA[i]) / dx;
+        const double CC_grad_back = (CC[i] - um[1]) / dx, CC_grad_forw = (up[1] - CC[i]) / dx;
+        const double cCa_grad_back = (cCa[i] - um[2]) / dx, cCa_grad_forw = (up[2] - cCa[i]) / dx;
+        const double cCa_laplace = (um[2] - 2 * cCa[i] + up[2]) * lap_scale;
+        const double cCO3_grad_back = (cCO3[i] - um[3]) / dx, cCO3_grad_forw = (up[3] - cCO3[i]) / dx;
+        const double cCO3_laplace = (um[3] - 2 * cCO3[i] + up[3]) * lap_scale;
+        const double Phi_grad_back = (Phi[i] - um[4]) / dx, Phi_grad_forw = (up[4] - Phi[i]) / dx;
+        const double Phi_laplace = (um[4] - 2 * Phi[i] + up[4]) * lap_scale;
+
+        const double F = 1 - exp(10 - 10 / Phi[i]);                                         /* :414 */
+        const double U = c->presum + c->rhorat * pow(Phi[i], 3) * F / (1 - Phi[i]);         /* :416 */
+        double CA_grad, CC_grad;
+        if (U > 0) { CA_grad = CA_grad_back; CC_grad = CC_grad_back; }                      /* :418-423 */
+        else       { CA_grad = CA_grad_forw; CC_grad = CC_grad_forw; }
+        const double W = c->presum - c->rhorat * pow(Phi[i], 2) * F;                        /* :425 */
+        const double denominator = 1 - 2 * log(Phi[i]);                                     /* :428 */
+        const double one_minus_Phi = 1 - Phi[i];                                            /* :429 */
+        const double dPhi = c->dPhi_fixed;                                                  /* :431 */
+
+        double sigma_cCa = 0, sigma_cCO3 = 0, sigma_Phi = 0;
+        if (p->FV_switch) {                                                                 /* :433-458 */
+            const double Peclet_cCa = W * c->delta_x * denominator / (2. * c->dCa);
+            sigma_cCa = orc_sigma(Peclet_cCa, W, c->Peclet_min, c->Peclet_max);
+            const double Peclet_cCO3 = W * c->delta_x * denominator / (2. * c->dCO3);
+            sigma_cCO3 = orc_sigma(Peclet_cCO3, W, c->Peclet_min, c->Peclet_max);
+            const double Peclet_Phi = W * c->delta_x / (2. * dPhi);
+            sigma_Phi = orc_sigma(Peclet_Phi, W, c->Peclet_min, c->Peclet_max);
+        }
+        const double cCa_grad = 0.5 * ((1 - sigma_cCa) * cCa_grad_forw + (1 + sigma_cCa) * cCa_grad_back);     /* :464 */
+        const double cCO3_grad = 0.5 * ((1 - sigma_cCO3) * cCO3_grad_forw + (1 + sigma_cCO3) * cCO3_grad_back); /* :466 */
+        const double Phi_grad = 0.5 * ((1 - sigma_Phi) * Phi_grad_forw + (1 + sigma_Phi) * Phi_grad_back);     /* :468 */
+
+        const double common_helper1 = Phi[i] / denominator;                                 /* :471 */
+        const double common_helper2 = Phi_grad * (2 + denominator) / pow(denominator, 2);   /* :472-473 */
+        const double helper_cCa_grad = c->dCa * (common_helper2 * cCa_grad + common_helper1 * cCa_laplace);    /* :474 */
+        const double helper_cCO3_grad = c->dCO3 * (common_helper2 * cCO3_grad + common_helper1 * cCO3_laplace); /* :476 */
+
+        const double two_factors = cCa[i] * cCO3[i];                                        /* :479 */
+        const double two_factors_upp_lim = (1.0 < two_factors) ? 1.0 : two_factors;         /* min(x,1) :480 */
+        const double two_factors_low_lim = (1.0 > two_factors) ? 1.0 : two_factors;         /* max(x,1) :481 */
+        const double three_factors = two_factors * c->KRat;                                 /* :482 */
+        const double three_factors_upp_lim = (1.0 < three_factors) ? 1.0 : three_factors;
+        const double three_factors_low_lim = (1.0 > three_factors) ? 1.0 : three_factors;
+
+        const double coA = CA[i] * ((pow(1 - three_factors_upp_lim, p->m2)) * orc_mask(p, dx, i)
+                                    - c->nu1 * pow(three_factors_low_lim - 1, p->m1));       /* :486-488 */
+        const double coC = CC[i] * ((pow(two_factors_low_lim - 1, p->n1))
+                                    - c->nu2 * pow(1 - two_factors_upp_lim, p->n2));         /* :490-491 */
+        const double common_helper3 = coA - c->lambda_ * coC;                               /* :493 */
+        const double dW_dx = -c->rhorat * Phi_grad * (2 * Phi[i] * F + 10 * (F - 1));       /* :495 */
+
+        rate[i] = -U * CA_grad - c->Da * ((1 - CA[i]) * coA + c->lambda_ * CA[i] * coC);    /* :498-499 */
+        rate[N + i] = -U * CC_grad + c->Da * (c->lambda_ * (1 - CC[i]) * coC + CC[i] * coA); /* :502-503 */
+        rate[2 * N + i] = helper_cCa_grad / Phi[i] - W * cCa_grad
+                          + c->Da * one_minus_Phi * (c->delta - cCa[i]) * common_helper3 / Phi[i];   /* :506-509 */
+        rate[3 * N + i] = helper_cCO3_grad / Phi[i] - W * cCO3_grad
+                          + c->Da * one_minus_Phi * (c->delta - cCO3[i]) * common_helper3 / Phi[i];  /* :512-515 */
+        rate[4 * N + i] = -(dW_dx * Phi[i] + W * Phi_grad) + dPhi * Phi_laplace
+                          + c->Da * one_minus_Phi * common_helper3;                         /* :518-520 */
+    }
+}
+
+void marl_oracle_rhs(const marl_params *p, int64_t N, const double *y, double *rate)
+{
+    orc_consts c;
+    orc_derive(p, N, &c);
+    orc_rhs(p, &c, N, y, rate);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * The seven monitors.  marlpde/LHeureux_model.py:524-593.  NaN propagates like np.amin/amax.
+ * ---------------------------------------------------------------------------------------- */
+static void orc_events(const marl_params *p, const orc_consts *c, int64_t N, const double *y, double out[MARL_NEVENTS])
+{
+    (void)p;
+    double mn_all = INFINITY, mn_CA = INFINITY, mn_CC = INFINITY, mx_sum = -INFINITY, mx_Phi = -INFINITY;
+    double mn_U = INFINITY, mx_W = -INFINITY;
+    int nan_all = 0, nan_CA = 0, nan_CC = 0, nan_sum = 0, nan_Phi = 0, nan_U = 0, nan_W = 0;
+    for (int64_t i = 0; i < NF * N; i++) {
+        if (y[i] != y[i]) nan_all = 1;
+        if (y[i] < mn_all) mn_all = y[i];
+    }
+    for (int64_t i = 0; i < N; i++) {
+        const double CA = y[i], CC = y[N + i], Phi = y[4 * N + i];
+        const double s = CA + CC;
+        const double F = 1 - exp(10 - 10 / Phi);                                  /* :574, :588 */
+        const double U = c->presum + c->rhorat * pow(Phi, 3) * F / (1 - Phi);     /* :575 */
+        const double W = c->presum - c->rhorat * pow(Phi, 2) * F;                 /* :589 */
+        if (CA != CA) nan_CA = 1;
+        if (CC != CC) nan_CC = 1;
+        if (s != s) nan_sum = 1;
+        if (Phi != Phi) nan_Phi = 1;
+        if (U != U) nan_U = 1;
+        if (W != W) nan_W = 1;
+        if (CA < mn_CA) mn_CA = CA;
+        if (CC < mn_CC) mn_CC = CC;
+        if (s > mx_sum) mx_sum = s;
+        if (Phi > mx_Phi) mx_Phi = Phi;
+        if (U < mn_U) mn_U = U;
+        if (W > mx_W) mx_W = W;
+    }
+    out[0] = nan_all ? NAN : mn_all;          /* zeros            :530 */
+    out[1] = nan_CA ? NAN : mn_CA;            /* zeros_CA         :538 */
+    out[2] = nan_CC ? NAN : mn_CC;            /* zeros_CC         :546 */
+    out[3] = nan_sum ? NAN : mx_sum - 1;      /* ones_CA_plus_CC  :556 */
+    out[4] = nan_Phi ? NAN : mx_Phi - 1;      /* ones_Phi         :565 */
+    out[5] = nan_U ? NAN : mn_U;              /* zeros_U          :579 */
+    out[6] = nan_W ? NAN : mx_W;              /* zeros_W          :593 */
+}
+
+void marl_oracle_events(const marl_params *p, int64_t N, const double *y, double out[MARL_NEVENTS])
+{
+    orc_consts c;
+    orc_derive(p, N, &c);
+    orc_events(p, &c, N, y, out);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Classical fixed-step RK4 (BASELINE config 2; not in the reference - README.md:9 only notes
+ * that forward Euler fails).  Stage and update arithmetic is the contract the HIP kernel follows:
+ *   k1 = f(y); k2 = f(y + (dt/2) k1); k3 = f(y + (dt/2) k2); k4 = f(y + dt k3)
+ *   y <- y + (dt/6) * (((k1 + 2 k2) + 2 k3) + k4)
+ * ---------------------------------------------------------------------------------------- */
+int marl_oracle_rk4(const marl_params *p, int64_t N, double *y, double dt, int64_t nsteps)
+{
+    orc_consts c;
+    orc_derive(p, N, &c);
+    const int64_t n = NF * N;
+    double *buf = (double *)malloc(sizeof(double) * n * 3);
+    if (!buf) return -1;
+    double *k = buf, *acc = buf + n, *ys = buf + 2 * n;
+    const double h2 = 0.5 * dt, h6 = dt / 6.0;
+    for (int64_t s = 0; s < nsteps; s++) {
+        orc_rhs(p, &c, N, y, k);
+        for (int64_t i = 0; i < n; i++) { acc[i] = k[i]; ys[i] = y[i] + h2 * k[i]; }
+        orc_rhs(p, &c, N, ys, k);
+        for (int64_t i = 0; i < n; i++) { acc[i] = acc[i] + 2.0 * k[i]; ys[i] = y[i] + h2 * k[i]; }
+        orc_rhs(p, &c, N, ys, k);
+        for (int64_t i = 0; i < n; i++) { acc[i] = acc[i] + 2.0 * k[i]; ys[i] = y[i] + dt * k[i]; }
+        orc_rhs(p, &c, N, ys, k);
+        for (int64_t i = 0; i < n; i++) y[i] = y[i] + h6 * (acc[i] + k[i]);
+    }
+    free(buf);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Adaptive Dormand-Prince 5(4) exactly as scipy drives it for the reference
+ * (call site marlpde/Evolve_scenario.py:104-109; algorithm scipy/integrate/_ivp/rk.py:14-71
+ * rk_step, :111-176 _step_impl, :377-407 tableau + dense output P, common.py:63-65 RMS norm,
+ * ivp.py:654-723 driver incl. events and t_eval).
+ * ---------------------------------------------------------------------------------------- */
+static const double DP_C[6] = {0, 1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1};
+static const double DP_A[6][5] = {
+    {0, 0, 0, 0, 0},
+    {1.0 / 5, 0, 0, 0, 0},
+    {3.0 / 40, 9.0 / 40, 0, 0, 0},
+    {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0},
+    {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0},
+    {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656}};
+static const double DP_B[6] = {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84};
+static const double DP_E[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 17253.0 / 339200, -22.0 / 525, 1.0 / 40};
+static const double DP_P[7][4] = {
+    {1, -8048581381.0 / 2820520608, 8663915743.0 / 2820520608, -12715105075.0 / 11282082432},
+    {0, 0, 0, 0},
+    {0, 131558114200.0 / 32700410799, -68118460800.0 / 10900136933, 87487479700.0 / 32700410799},
+    {0, -1754552775.0 / 470086768, 14199869525.0 / 1410260304, -10690763975.0 / 1880347072},
+    {0, 127303824393.0 / 49829197408, -318862633887.0 / 49829197408, 701980252875.0 / 199316789632},
+    {0, -282668133.0 / 205662961, 2019193451.0 / 616988883, -1453857185.0 / 822651844},
+    {0, 40617522.0 / 29380423, -110615467.0 / 29380423, 69997945.0 / 29380423}};
+
+#define DP_SAFETY 0.9
+#define DP_MIN_FACTOR 0.2
+#define DP_MAX_FACTOR 10.0
+
+typedef struct {
+    const marl_params *p;
+    const orc_consts *c;
+    int64_t N;
+    double t_old, h;
+    const double *y_old;
+    const double *K; /* 7 x 5N */
+    double *scratch; /* 5N */
+} orc_dense;
+
+/* RkDenseOutput._call_impl, rk.py:560-574:  y(t) = y_old + h * Q . [x, x^2, x^3, x^4],  Q = K^T P */
+static void orc_dense_eval(const orc_dense *d, double t, double *out)
+{
+    const int64_t n = NF * d->N;
+    const double x = (t - d->t_old) / d->h;
+    double pw[4];
+    pw[0] = x;
+    for (int m = 1; m < 4; m++) pw[m] = pw[m - 1] * x;
+    for (int64_t i = 0; i < n; i++) {
+        double acc = 0;
+        for (int m = 0; m < 4; m++) {
+            double q = 0;
+            for (int s = 0; s < 7; s++) q += d->K[s * n + i] * DP_P[s][m];
+            acc += q * pw[m];
+        }
+        out[i] = d->h * acc + d->y_old[i];
+    }
+}
+
+static double orc_event_at(const orc_dense *d, int which, double t)
+{
+    double g[MARL_NEVENTS];
+    orc_dense_eval(d, t, d->scratch);
+    orc_events(d->p, d->c, d->N, d->scratch, g);
+    return g[which];
+}
+
+/* Brent's method on [a, b] with xtol = rtol = 4 eps (ivp.py:51-76 -> scipy.optimize.brentq). */
+static double orc_brent(const orc_dense *d, int which, double a, double b)
+{
+    const double xtol = 4 * 2.220446049250313e-16, rtol = xtol;
+    double fa = orc_event_at(d, which, a), fb = orc_event_at(d, which, b);
+    if (fa == 0) return a;
+    if (fb == 0) return b;
+    double xpre = a, xcur = b, fpre = fa, fcur = fb, xblk = 0, fblk = 0, spre = 0, scur = 0;
+    for (int it = 0; it < 100; it++) {
+        if (fpre != 0 && fcur != 0 && ((fpre < 0) != (fcur < 0))) {
+            xblk = xpre; fblk = fpre; spre = scur = xcur - xpre;
+        }
+        if (fabs(fblk) < fabs(fcur)) {
+            xpre = xcur; xcur = xblk; xblk = xpre;
+            fpre = fcur; fcur = fblk; fblk = fpre;
+        }
+        const double delta = (xtol + rtol * fabs(xcur)) / 2;
+        const double sbis = (xblk - xcur) / 2;
+        if (fcur == 0 || fabs(sbis) < delta) return xcur;
+        if (fabs(spre) > delta && fabs(fcur) < fabs(fpre)) {
+            double stry;
+            if (xpre == xblk) {
+                stry = -fcur * (xcur - xpre) / (fcur - fpre);
+            } else {
+                const double dpre = (fpre - fcur) / (xpre - xcur), dblk = (fblk - fcur) / (xblk - xcur);
+                stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
+            }
+            if (2 * fabs(stry) < fmin(fabs(spre), 3 * fabs(sbis) - delta)) { spre = scur; scur = stry; }
+            else { spre = sbis; scur = sbis; }
+        } else { spre = sbis; scur = sbis; }
+        xpre = xcur; fpre = fcur;
+        if (fabs(scur) > delta) xcur += scur;
+        else xcur += (sbis > 0 ? delta : -delta);
+        fcur = orc_event_at(d, which, xcur);
+    }
+    return xcur;
+}
+
+/* y: in = y(t0), out = state at the time reached.  t_eval (sorted, within [t0,t1]) may be NULL.
+ * y_eval: n_eval x 5N row-major (sample-major).  step_times: optional buffer receiving the
+ * accepted step end times (capacity max_steps_out; *n_steps_out entries written).
+ * t_events: optional 7 x max_events buffer of root times.  Returns stats->status. */
+int marl_oracle_rk45(const marl_params *p, int64_t N, double *y, double t0, double t1, double first_step,
+                     double rtol, double atol, const double *t_eval, int64_t n_eval, double *y_eval,
+                     double *step_times, int64_t max_steps_out, int64_t *n_steps_out,
+                     double *t_events, int64_t max_events, int64_t max_attempts, marl_stats *st)
+{
+    orc_consts c;
+    orc_derive(p, N, &c);
+    const int64_t n = NF * N;
+    double *buf = (double *)malloc(sizeof(double) * n * 11);
+    if (!buf) return -2;
+    double *K = buf, *ynew = buf + 7 * n, *ys = buf + 8 * n, *yold = buf + 9 * n, *scratch = buf + 10 * n;
+    double g[MARL_NEVENTS], g_new[MARL_NEVENTS];
+    memset(st, 0, sizeof *st);
+    int64_t steps_out = 0, eval_i = 0, attempts = 0;
+
+    double t = t0, h_abs = first_step;                   /* rk.py:94-100 (first_step validated) */
+    orc_rhs(p, &c, N, y, K);                             /* self.f = fun(t0, y0) */
+    st->nfev = 1;
+    orc_events(p, &c, N, y, g);                          /* ivp.py:645 g = [event(t0, y0)] */
+    int status = 1;                                      /* 1 = running (internal) */
+
+    while (status == 1) {
+        if (t == t1) { status = 0; break; }              /* base.py:189-194 */
+        /* ---- _step_impl, rk.py:111-176 ---- */
+        const double min_step = 10 * fabs(nextafter(t, INFINITY) - t);
+        if (h_abs < min_step) h_abs = min_step;          /* max_step = inf */
+        int accepted = 0, rejected = 0;
+        double h = 0, t_new = t;
+        while (!accepted) {
+            if (h_abs < min_step) { status = -1; break; }
+            if (max_attempts > 0 && attempts >= max_attempts) { status = 2; break; }
+            attempts++;
+            h = h_abs;
+            t_new = t + h;
+            if (t_new - t1 > 0) t_new = t1;
+            h = t_new - t;
+            h_abs = fabs(h);
+            /* rk_step, rk.py:61-69; K[0] = f is already in place (FSAL) */
+            for (int s = 1; s < 6; s++) {
+                for (int64_t i = 0; i < n; i++) {
+                    double dot = 0;
+                    for (int j = 0; j < s; j++) dot += K[j * n + i] * DP_A[s][j];
+                    ys[i] = y[i] + dot * h;
+                }
+                orc_rhs(p, &c, N, ys, K + s * n);
+            }
+            for (int64_t i = 0; i < n; i++) {
+                double dot = 0;
+                for (int j = 0; j < 6; j++) dot += K[j * n + i] * DP_B[j];
+                ynew[i] = y[i] + h * dot;
+            }
+            orc_rhs(p, &c, N, ynew, K + 6 * n);
+            st->nfev += 6;
+            /* error norm, rk.py:103-107, 146-147; common.py:63-65 */
+            double ss = 0;
+            for (int64_t i = 0; i < n; i++) {
+                double dot = 0;
+                for (int j = 0; j < 7; j++) dot += K[j * n + i] * DP_E[j];
+                const double ay = fabs(y[i]), an = fabs(ynew[i]);
+                const double scale = atol + (ay > an || ay != ay ? ay : an) * rtol; /* np.maximum propagates NaN */
+                const double e = dot * h / scale;
+                ss += e * e;
+            }
+            const double error_norm = sqrt(ss) / sqrt((double)n);
+            if (error_norm < 1) {
+                double factor = (error_norm == 0) ? DP_MAX_FACTOR : fmin(DP_MAX_FACTOR, DP_SAFETY * pow(error_norm, -0.2));
+                if (rejected) factor = fmin(1.0, factor);
+                h_abs *= factor;
+                accepted = 1;
+            } else {
+                const double f = DP_SAFETY * pow(error_norm, -0.2);
+                h_abs *= (f > DP_MIN_FACTOR) ? f : DP_MIN_FACTOR; /* max(0.2, nan) -> 0.2 */
+                rejected = 1;
+                st->n_rejected++;
+            }
+        }
+        if (status != 1) break;
+        st->n_accepted++;
+        memcpy(yold, y, sizeof(double) * n);
+        memcpy(y, ynew, sizeof(double) * n);
+        const double t_old = t;
+        t = t_new;
+        if (t - t1 >= 0) status = 0;                     /* base.py:203-204 */
+        if (step_times && steps_out < max_steps_out) step_times[steps_out] = t;
+        steps_out++;
+
+        orc_dense dense = {p, &c, N, t_old, h, yold, K, scratch};
+        /* events, ivp.py:673-694 + find_active_events :131-156 (direction 0, non-terminal) */
+        orc_events(p, &c, N, y, g_new);
+        for (int e = 0; e < MARL_NEVENTS; e++) {
+            const int up = (g[e] <= 0) && (g_new[e] >= 0), down = (g[e] >= 0) && (g_new[e] <= 0);
+            if (up || down) {
+                if (t_events && st->n_events[e] < max_events)
+                    t_events[e * max_events + st->n_events[e]] = orc_brent(&dense, e, t_old, t);
+                st->n_events[e]++;
+            }
+            g[e] = g_new[e];
+        }
+        /* t_eval, ivp.py:706-723: samples in (t_old, t] (t0 itself is emitted on the first step) */
+        while (t_eval && eval_i < n_eval && t_eval[eval_i] <= t) {
+            orc_dense_eval(&dense, t_eval[eval_i], y_eval + eval_i * n);
+            eval_i++;
+        }
+        memcpy(K, K + 6 * n, sizeof(double) * n);        /* self.f = f_new */
+    }
+    st->status = status;
+    st->t = t;
+    st->h_next = h_abs;
+    orc_events(p, &c, N, y, st->event_value);
+    if (n_steps_out) *n_steps_out = steps_out;
+    free(buf);
+    return status;
+}
+
+/* Batched sweep = the same integrators over `batch` independent instances (params[b], y + b*5N).
+ * Not in the reference (it runs one scenario per process); BASELINE configs 3-4. */
+int marl_oracle_rk4_batch(const marl_params *p, int64_t batch, int64_t N, double *y, const double *dt, int64_t nsteps)
+{
+    int rc = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic) if (batch > 1)
+#endif
+    for (int64_t b = 0; b < batch; b++) {
+        int r = marl_oracle_rk4(&p[b], N, y + b * NF * N, dt[b], nsteps);
+        if (r) rc = r;
+    }
+    return rc;
+}
