@@ -9,8 +9,10 @@
  *   - all floating point data is float64; a state vector is float64[5*N] FIELD-MAJOR
  *     (CA | CC | cCa | cCO3 | Phi, each N contiguous: marlpde/Evolve_scenario.py:64-65,76-86) unless a
  *     `layout` argument says MARL_LAYOUT_TILED (device buffers only);
- *   - functions return 0 on success, <0 on error (invalid argument / HIP failure; text from
- *     marl_last_error), and the solver status where documented;
+ *   - functions return 0 when they ran, <0 on error (invalid argument / HIP failure; text from
+ *     marl_last_error); how an integration ENDED is in marl_stats.status (0 reached t1, -1 step size
+ *     too small = scipy's status -1, 2 attempt budget exhausted) - a failed solve is not an API error,
+ *     exactly as solve_ivp reports it in sol.status without raising (scipy/integrate/_ivp/ivp.py:659-661);
  *   - `*_dev` variants take DEVICE pointers (e.g. torch.Tensor.data_ptr()), enqueue on the context's
  *     stream and do not synchronise unless documented; the others take HOST pointers, copy in/out
  *     and return after the stream is idle;
@@ -42,7 +44,10 @@ int marl_ctx_create(const marl_params* params, int64_t n_instances, int64_t N, i
 
 void marl_ctx_destroy(marl_ctx* ctx);
 const char* marl_last_error(const marl_ctx* ctx); /* ctx may be NULL: error of the last failed create */
-int marl_set_stream(marl_ctx* ctx, void* hip_stream); /* NULL = the context's own stream */
+/* All work of a context is enqueued on one HIP stream: by default the device's default (null) stream -
+ * which is also PyTorch's default current stream - or the one given here (a hipStream_t, e.g.
+ * torch.cuda.current_stream().cuda_stream; NULL selects the default stream again). */
+int marl_set_stream(marl_ctx* ctx, void* hip_stream);
 int marl_synchronize(marl_ctx* ctx);
 /* Tuning knobs (kernel variant selection); unknown names are an error.  See DESIGN.md. */
 int marl_set_option(marl_ctx* ctx, const char* name, int64_t value);
@@ -83,7 +88,7 @@ int marl_sweep_rk4_dev(marl_ctx* ctx, double* y_dev, const double* dt, int64_t n
  * t_eval (may be NULL): sorted sample times within [t0, t1]; y_eval receives n_eval x 5N doubles,
  * sample-major (dense output, rk.py:560-574).  t_events (may be NULL): 7 x max_events root times of the
  * monitors' sign changes, located like scipy does (dense output + Brent, ivp.py:51-76); the counts are
- * stats->n_events.  max_attempts = 0: unlimited.  Returns stats->status. */
+ * stats->n_events.  max_attempts = 0: unlimited. */
 int marl_integrate_rk45(marl_ctx* ctx, double* y, double t0, double t1, double first_step, double rtol, double atol,
                         const double* t_eval, int64_t n_eval, double* y_eval, double* t_events, int64_t max_events,
                         int64_t max_attempts, marl_stats* stats);

@@ -79,6 +79,14 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise MarlError(f"{LIB_PATH} not found: build the HIP extension first (__graft_entry__.build()); "
                             "this package has no CPU fallback")
+        # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME
+        # libamdhip64.so.7, the same as /opt/rocm's).  Loaded first, it satisfies this library's
+        # DT_NEEDED by SONAME; loaded second, it would come up as a SECOND runtime beside the system
+        # one and torch.cuda would find no device.  So torch (the device-buffer provider) goes first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)

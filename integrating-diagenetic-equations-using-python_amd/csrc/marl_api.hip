@@ -20,7 +20,7 @@ static std::string g_create_error;
 
 struct marl_ctx {
     int device = 0;
-    hipStream_t stream = nullptr, own_stream = nullptr;
+    hipStream_t stream = nullptr;  // nullptr = the device's default (null) stream, which is also torch's default current stream
     int64_t N = 0, batch = 0;
     Slab slab{};
     std::vector<marl_params> params;
@@ -179,8 +179,6 @@ int marl_ctx_create(const marl_params* params, int64_t n_instances, int64_t N, i
         }                                                                                   \
     } while (0)
     CREATE_OK(hipSetDevice(device));
-    CREATE_OK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
-    ctx->stream = ctx->own_stream;
     CREATE_OK(hipMalloc((void**)&ctx->dconsts, sizeof(DevConsts) * n_instances));
     CREATE_OK(hipMemcpy(ctx->dconsts, ctx->hconsts.data(), sizeof(DevConsts) * n_instances, hipMemcpyHostToDevice));
     CREATE_OK(hipMalloc((void**)&ctx->rec, sizeof(double) * NQ * n_instances));
@@ -197,7 +195,7 @@ void marl_ctx_destroy(marl_ctx* ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    (void)hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < 4; i++)
         if (ctx->buf[i]) (void)hipFree(ctx->buf[i]);
     if (ctx->part) (void)hipFree(ctx->part);
@@ -207,7 +205,6 @@ void marl_ctx_destroy(marl_ctx* ctx)
     if (ctx->dconsts) (void)hipFree(ctx->dconsts);
     if (ctx->hctrl) (void)hipHostFree(ctx->hctrl);
     if (ctx->hrec) (void)hipHostFree(ctx->hrec);
-    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
 
@@ -216,7 +213,7 @@ const char* marl_last_error(const marl_ctx* ctx) { return ctx ? ctx->err.c_str()
 int marl_set_stream(marl_ctx* ctx, void* hip_stream)
 {
     if (!ctx) return -1;
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream;
     return 0;
 }
 
@@ -792,7 +789,7 @@ int marl_integrate_rk45_dev(marl_ctx* ctx, double* y_dev, int layout, double t0,
     if (int rc = rk45_run(ctx, layout, false, t0, t1, first_step, rtol, atol, nullptr, 0, nullptr, nullptr, 0, max_attempts, stats)) return rc;
     HIP_OK(ctx, hipMemcpyAsync(y_dev, ctx->buf[0], sd * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
-    return stats->status;
+    return 0;
 }
 
 int marl_integrate_rk45(marl_ctx* ctx, double* y, double t0, double t1, double first_step, double rtol, double atol,
@@ -828,7 +825,7 @@ int marl_integrate_rk45(marl_ctx* ctx, double* y, double t0, double t1, double f
         if (rc == 0 && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, -3, "sync failed");
     }
     if (yev) (void)hipFree(yev);
-    return rc ? rc : stats->status;
+    return rc;
 }
 
 }  // extern "C"

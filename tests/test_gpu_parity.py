@@ -1,0 +1,348 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle and the committed
+golden vectors (which come from the reference's own code, oracle/make_goldens.py).
+
+Tolerances (fp64).  The device evaluates the same formulas with fused multiply-adds, Newton
+reciprocals instead of divisions, and pow(b, e) = exp(e log b); none of these is bit-identical to
+numpy/libm, so results are compared relative to each field's max |value|:
+  RHS                          <= 2e-13   (one evaluation; observed ~1e-15 .. 1e-14)
+  RK4 / RK45 short runs        <= 1e-10   (tens to hundreds of steps; the system is dissipative)
+  RK45 step sequence           identical accept/reject sequence, nfev equal
+  end-to-end vs HDF5 goldens   the reference's own rtol 0.1 / atol 0.01 (tests/Regression_test/test_regression.py:29-30)
+"""
+import numpy as np
+import pytest
+
+from common import GOLDEN, noisy_state, parse_key, rel_to_max, scenario, synthetic_state
+
+pytestmark = pytest.mark.gpu
+
+RHS_TOL = 2e-13
+RUN_TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def make_model(p):
+    from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
+    return LMAHeureuxPorosityDiff.from_scenario(p, device=0)
+
+
+def test_library_loaded_is_in_tree():
+    from marlpde_amd import _abi
+    lib = _abi.load()
+    assert "integrating-diagenetic-equations-using-python_amd/csrc/libmarl_hip.so" in lib._name
+
+
+def test_derived_constants_match_reference():
+    import json
+    gold = json.load(open(f"{GOLDEN}/derived_constants.json"))
+    for name in ("default", "A", "matlab", "stiffphi"):
+        eq = make_model(scenario(name))
+        for k, v in gold[name].items():
+            if k == "mask_cells":
+                assert list(range(eq.mask_lo, eq.mask_hi)) == v
+            else:
+                assert getattr(eq, k) == pytest.approx(v, rel=1e-15, abs=0), (name, k)
+        eq.close()
+
+
+def test_rhs_and_events_against_reference_vectors():
+    g = np.load(f"{GOLDEN}/rhs_vectors.npz")
+    worst = 0.0
+    for key in g["index"]:
+        s, st, fv, N = parse_key(key)
+        eq = make_model(scenario(s, N, fv))
+        y = g[f"{key}|y"]
+        r = eq.fun(0.0, y, None, None, None)
+        assert r is not y and r.shape == y.shape
+        err = rel_to_max(r, g[f"{key}|rate"])
+        worst = max(worst, err)
+        assert err <= RHS_TOL, (key, err)
+        ev = eq.events_all(y)[0]
+        ref = g[f"{key}|events"]
+        assert np.max(np.abs(ev - ref) / np.maximum(1.0, np.abs(ref))) <= 1e-13, (key, ev, ref)
+        # the scipy-style callables agree with the batched call
+        assert eq.zeros_W(0.0, y) == ev[6] and eq.zeros(0.0, y) == ev[0]
+        eq.close()
+    print(f"worst RHS rel-to-max error over {len(g['index'])} reference vectors: {worst:.2e}")
+
+
+@pytest.mark.parametrize("N", [200, 1000, 4096, 65536])
+def test_rhs_device_layouts_against_oracle(torch_cuda, oracle, N):
+    torch = torch_cuda
+    from marlpde_amd._abi import LAYOUT_FIELD_MAJOR, LAYOUT_TILED
+    p = scenario("A", N)
+    eq = make_model(p)
+    eq.use_stream(torch.cuda.current_stream().cuda_stream)
+    y = noisy_state(p, N, seed=N)
+    ref = oracle.rhs(oracle.params_from_model(eq), N, y)
+    yd = torch.from_numpy(y).cuda()
+    out = torch.empty_like(yd)
+    eq.rhs_device(yd.data_ptr(), out.data_ptr(), LAYOUT_FIELD_MAJOR)
+    torch.cuda.synchronize()
+    assert rel_to_max(out.cpu().numpy(), ref) <= RHS_TOL
+    # tiled layout: convert, evaluate, convert back
+    nt = eq.state_doubles(LAYOUT_TILED)
+    yt = torch.zeros(nt, dtype=torch.float64, device="cuda")
+    rt = torch.zeros(nt, dtype=torch.float64, device="cuda")
+    eq.convert_layout_device(yd.data_ptr(), yt.data_ptr(), LAYOUT_FIELD_MAJOR, LAYOUT_TILED)
+    eq.rhs_device(yt.data_ptr(), rt.data_ptr(), LAYOUT_TILED)
+    back = torch.empty_like(yd)
+    eq.convert_layout_device(rt.data_ptr(), back.data_ptr(), LAYOUT_TILED, LAYOUT_FIELD_MAJOR)
+    torch.cuda.synchronize()
+    assert rel_to_max(back.cpu().numpy(), ref) <= RHS_TOL
+    # round trip of the layout conversion is exact
+    rt2 = torch.empty_like(yd)
+    eq.convert_layout_device(yt.data_ptr(), rt2.data_ptr(), LAYOUT_TILED, LAYOUT_FIELD_MAJOR)
+    torch.cuda.synchronize()
+    assert torch.equal(rt2, yd)
+    assert np.allclose(eq.events_device(yd.data_ptr())[0], oracle.events(oracle.params_from_model(eq), N, y), rtol=1e-13, atol=1e-13)
+    eq.close()
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("variant", range(10))
+def test_rk4_fused_variants_against_oracle(torch_cuda, oracle, variant, layout):
+    """Every fused-RK4 instantiation (block size, cells/thread, steps/launch) on a grid that is not a
+    multiple of any tile, incl. a step count that is not a multiple of the fused depth."""
+    torch = torch_cuda
+    from marlpde_amd._abi import LAYOUT_FIELD_MAJOR
+    N, nsteps = 5003, 11
+    p = scenario("default", N)
+    eq = make_model(p)
+    eq.use_stream(torch.cuda.current_stream().cuda_stream)
+    eq.set_option("rk4_variant", variant)
+    y = synthetic_state(p, N, amplitude=0.05)
+    dt = 0.25 * (eq.Depths.length / N) ** 2
+    ref = oracle.rk4(oracle.params_from_model(eq), N, y, dt, nsteps)
+    yd = torch.from_numpy(y).cuda()
+    if layout == LAYOUT_FIELD_MAJOR:
+        eq.integrate_rk4_device(yd.data_ptr(), dt, nsteps, layout)
+        got = yd
+    else:
+        yt = torch.zeros(eq.state_doubles(layout), dtype=torch.float64, device="cuda")
+        eq.convert_layout_device(yd.data_ptr(), yt.data_ptr(), 0, layout)
+        eq.integrate_rk4_device(yt.data_ptr(), dt, nsteps, layout)
+        got = torch.empty_like(yd)
+        eq.convert_layout_device(yt.data_ptr(), got.data_ptr(), layout, 0)
+    torch.cuda.synchronize()
+    assert rel_to_max(got.cpu().numpy(), ref) <= RUN_TOL
+    eq.close()
+
+
+@pytest.mark.parametrize("name,N", [("default", 200), ("A", 200), ("matlab", 1024), ("stiffphi", 64), ("A", 3000)])
+def test_rk4_host_entry_against_oracle(oracle, name, N):
+    """marl_integrate_rk4 (host pointers): small grids take the one-workgroup on-chip path, larger ones the fused path."""
+    p = scenario(name, N)
+    eq = make_model(p)
+    y = noisy_state(p, N, seed=1, sigma=0.02)
+    dt = 0.2 * (eq.Depths.length / N) ** 2
+    got = eq.integrate_rk4(y, dt, 25)
+    ref = oracle.rk4(oracle.params_from_model(eq), N, y, dt, 25)
+    assert rel_to_max(got, ref) <= RUN_TOL
+    eq.close()
+
+
+@pytest.mark.parametrize("traj", ["rk45_traj_A_N200", "rk45_traj_default_N200", "rk45_traj_A_N64"])
+def test_rk45_reproduces_scipy_trajectory(traj):
+    """Same accepted/rejected sequence as scipy's RK45 on the reference RHS (golden from oracle/make_goldens.py)."""
+    g = np.load(f"{GOLDEN}/{traj}.npz")
+    name, N = traj.split("_")[2], int(traj.split("N")[-1])
+    eq = make_model(scenario(name, N))
+    te = g["t_eval"] if g["t_eval"].size else None
+    res = eq.integrate_rk45(g["y0"], tuple(g["t_span"]), float(g["first_step"]), float(g["rtol"]), float(g["atol"]), t_eval=te)
+    assert res.status == 0 and res.nfev == int(g["nfev"])
+    assert res.n_accepted == len(g["step_times"]) - 1
+    assert rel_to_max(res.y_final, g["y_final"]) <= 1e-9
+    if te is not None:
+        assert np.array_equal(res.t, g["t_eval"])
+        assert np.max(np.abs(res.y - g["y_eval"])) <= 1e-9
+    assert [len(e) for e in res.t_events] == list(g["n_events"])
+    eq.close()
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("variant", range(4))
+def test_rk45_fused_large_grid_against_oracle(torch_cuda, oracle, variant, layout):
+    torch = torch_cuda
+    N = 5003
+    p = scenario("A", N)
+    eq = make_model(p)
+    eq.use_stream(torch.cuda.current_stream().cuda_stream)
+    eq.set_option("rk45_variant", variant)
+    y = synthetic_state(p, N, amplitude=0.05)
+    dx2 = (eq.Depths.length / N) ** 2
+    t1 = 40 * dx2
+    yref, st, steps, _, _ = oracle.rk45(oracle.params_from_model(eq), N, y, 0.0, t1, 0.5 * dx2, 1e-5, 1e-7)
+    yd = torch.from_numpy(y).cuda()
+    if layout == 0:
+        res = eq.integrate_rk45_device(yd.data_ptr(), (0.0, t1), 0.5 * dx2, 1e-5, 1e-7, layout)
+        got = yd
+    else:
+        yt = torch.zeros(eq.state_doubles(layout), dtype=torch.float64, device="cuda")
+        eq.convert_layout_device(yd.data_ptr(), yt.data_ptr(), 0, layout)
+        res = eq.integrate_rk45_device(yt.data_ptr(), (0.0, t1), 0.5 * dx2, 1e-5, 1e-7, layout)
+        got = torch.empty_like(yd)
+        eq.convert_layout_device(yt.data_ptr(), got.data_ptr(), layout, 0)
+    torch.cuda.synchronize()
+    assert (res.status, res.n_accepted, res.n_rejected, res.nfev) == (st.status, st.n_accepted, st.n_rejected, st.nfev)
+    assert res.t_reached == t1
+    assert rel_to_max(got.cpu().numpy(), yref) <= RUN_TOL
+    eq.close()
+
+
+def test_rk45_host_entry_large_grid_t_eval_and_budget(oracle):
+    """Large-grid host entry: interior t_eval samples by dense output; attempt budget stops with status 2."""
+    N = 3000
+    p = scenario("default", N)
+    eq = make_model(p)
+    y = synthetic_state(p, N, amplitude=0.03)
+    dx2 = (eq.Depths.length / N) ** 2
+    t1 = 30 * dx2
+    te = np.array([0.0, 0.31 * t1, 0.5 * t1, t1])
+    P = oracle.params_from_model(eq)
+    yref, st, _, ye, _ = oracle.rk45(P, N, y, 0.0, t1, 0.4 * dx2, 1e-4, 1e-6, t_eval=te)
+    res = eq.integrate_rk45(y, (0.0, t1), 0.4 * dx2, 1e-4, 1e-6, t_eval=te)
+    assert res.status == 0 and res.nfev == st.nfev and res.n_accepted == st.n_accepted
+    assert np.array_equal(res.t, te)
+    assert np.array_equal(res.y[:, 0], y)
+    for j in range(len(te)):
+        assert rel_to_max(res.y[:, j], ye[j]) <= RUN_TOL, j
+    assert rel_to_max(res.y_final, yref) <= RUN_TOL
+    res2 = eq.integrate_rk45(y, (0.0, t1), 0.4 * dx2, 1e-4, 1e-6, max_attempts=7, events=False)
+    _, st2, _, _, _ = oracle.rk45(P, N, y, 0.0, t1, 0.4 * dx2, 1e-4, 1e-6, max_attempts=7)
+    assert res2.status == 2 == st2.status and res2.t_reached == pytest.approx(st2.t, rel=1e-12)
+    eq.close()
+
+
+def test_rk45_event_root_matches_oracle(oracle):
+    """A monitor that changes sign: a porosity dip makes min(U) negative at t0; the reaction term lifts the
+    porosity and zeros_U crosses zero at t ~ 1.2e-4.  Root times come from dense output + Brent on both sides
+    (scipy/integrate/_ivp/ivp.py:51-76, 673-694)."""
+    N = 400
+    p = scenario("default", N)
+    eq = make_model(p)
+    L = eq.Depths.length
+    x = eq.Depths.axes_coords[0]
+    y = eq.get_state(p["CAIni"], p["CCIni"], p["cCaIni"], p["cCO3Ini"], p["PhiIni"])
+    y[4] = 0.8 - 0.04 * np.exp(-((x - 0.5 * L) / (0.08 * L)) ** 2)
+    y = y.ravel()
+    dx2 = (L / N) ** 2
+    P = oracle.params_from_model(eq)
+    t1 = 1000 * dx2
+    yref, st, _, _, tev = oracle.rk45(P, N, y, 0.0, t1, 0.5 * dx2, 1e-5, 1e-7)
+    res = eq.integrate_rk45(y, (0.0, t1), 0.5 * dx2, 1e-5, 1e-7)
+    assert [len(e) for e in tev] == [0, 0, 0, 0, 0, 1, 0], "test state must trigger zeros_U exactly once"
+    assert [len(e) for e in res.t_events] == [len(e) for e in tev]
+    for a, b in zip(res.t_events, tev):
+        assert np.allclose(a, b, rtol=1e-9, atol=1e-12 * t1)
+    assert res.n_accepted == st.n_accepted and rel_to_max(res.y_final, yref) <= 1e-9
+    eq.close()
+
+
+def test_sweep_rk4_and_rk45_against_oracle(torch_cuda, oracle):
+    """Batched sweep: one workgroup per instance, per-instance parameters, dt and controller."""
+    torch = torch_cuda
+    from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
+    N, B = 1024, 24
+    base = scenario("default", N)
+    rng = np.random.default_rng(3)
+    inst = [{"Phi0": float(a), "PhiIni": float(b), "PhiNR": float(b), "k3": float(k), "k4": float(k)}
+            for a, b, k in zip(rng.uniform(0.5, 0.8, B), rng.uniform(0.5, 0.8, B), 10 ** rng.uniform(-2, -1, B))]
+    eq = LMAHeureuxPorosityDiff.from_scenario(base, device=0, instances=inst)
+    eq.use_stream(torch.cuda.current_stream().cuda_stream)
+    assert eq.n_instances == B
+    y0 = np.stack([synthetic_state(base | i, N, amplitude=0.02) for i in inst])
+    dx2 = (eq.Depths.length / N) ** 2
+    dts = rng.uniform(0.15, 0.3, B) * dx2
+    yd = torch.from_numpy(y0).cuda()
+    eq.sweep_rk4_device(yd.data_ptr(), dts, 20)
+    torch.cuda.synchronize()
+    got = yd.cpu().numpy()
+    for b in range(B):
+        ref = oracle.rk4(oracle.params_from_model(eq, b), N, y0[b], dts[b], 20)
+        assert rel_to_max(got[b], ref) <= RUN_TOL, b
+    # batched RHS and monitors
+    r = eq.fun(0.0, y0.ravel()).reshape(B, -1)
+    ev = eq.events_all(y0.ravel())
+    for b in (0, B // 2, B - 1):
+        P = oracle.params_from_model(eq, b)
+        assert rel_to_max(r[b], oracle.rhs(P, N, y0[b])) <= RHS_TOL
+        assert np.allclose(ev[b], oracle.events(P, N, y0[b]), rtol=1e-13, atol=1e-13)
+    # adaptive sweep with an attempt budget (the bench's configuration) and to a common end time
+    yd = torch.from_numpy(y0).cuda()
+    res = eq.sweep_rk45_device(yd.data_ptr(), (0.0, 1.0), 0.5 * dx2, 1e-3, 1e-3, max_attempts=60)
+    torch.cuda.synchronize()
+    got = yd.cpu().numpy()
+    for b in range(B):
+        yref, st, _, _, _ = oracle.rk45(oracle.params_from_model(eq, b), N, y0[b], 0.0, 1.0, 0.5 * dx2, 1e-3, 1e-3, max_attempts=60)
+        assert (res[b].status, res[b].n_accepted, res[b].n_rejected) == (2, st.n_accepted, st.n_rejected), b
+        assert res[b].t_reached == pytest.approx(st.t, rel=1e-12)
+        assert rel_to_max(got[b], yref) <= 1e-9, b
+    eq.close()
+
+
+def test_nan_state_is_data_not_error(oracle):
+    """Phi <= 0 gives NaN rates (log of a negative number) exactly where the reference's numba path does;
+    a NaN error norm is a rejected step with factor 0.2 (scipy/integrate/_ivp/rk.py:163-164)."""
+    N = 256
+    p = scenario("default", N)
+    eq = make_model(p)
+    y = synthetic_state(p, N)
+    y[4 * N + 17] = -0.1
+    r = eq.fun(0.0, y)
+    ref = oracle.rhs(oracle.params_from_model(eq), N, y)
+    assert np.array_equal(np.isnan(r), np.isnan(ref)) and np.isnan(r).any()
+    res = eq.integrate_rk45(y, (0.0, 1e-3), 1e-6, 1e-3, 1e-3, events=False)
+    _, st, _, _, _ = oracle.rk45(oracle.params_from_model(eq), N, y, 0.0, 1e-3, 1e-6, 1e-3, 1e-3)
+    assert res.status == st.status == -1 and res.n_accepted == st.n_accepted == 0
+    eq.close()
+
+
+def test_full_size_rk4_against_oracle_and_layout_agreement(torch_cuda, oracle):
+    """BASELINE headline size N = 2^20: a few fused steps against the oracle, and the two device layouts /
+    two kernel variants against each other."""
+    torch = torch_cuda
+    N, nsteps = 1 << 20, 4
+    p = scenario("default", N)
+    eq = make_model(p)
+    eq.use_stream(torch.cuda.current_stream().cuda_stream)
+    y = synthetic_state(p, N)
+    dt = 0.25 * (eq.Depths.length / N) ** 2
+    ref = oracle.rk4(oracle.params_from_model(eq), N, y, dt, nsteps, omp=True)
+    results = []
+    for variant, layout in ((2, 1), (2, 0), (0, 1), (6, 1)):
+        eq.set_option("rk4_variant", variant)
+        yd = torch.from_numpy(y).cuda()
+        buf = yd
+        if layout:
+            buf = torch.zeros(eq.state_doubles(layout), dtype=torch.float64, device="cuda")
+            eq.convert_layout_device(yd.data_ptr(), buf.data_ptr(), 0, layout)
+        eq.integrate_rk4_device(buf.data_ptr(), dt, nsteps, layout)
+        if layout:
+            eq.convert_layout_device(buf.data_ptr(), yd.data_ptr(), layout, 0)
+        torch.cuda.synchronize()
+        results.append(yd.cpu().numpy())
+        assert rel_to_max(results[-1], ref) <= RUN_TOL, (variant, layout)
+    for other in results[1:]:
+        assert rel_to_max(other, results[0]) <= 1e-13
+    eq.close()
+
+
+def test_integrate_equations_rk45_against_reference_golden():
+    """End-to-end drop-in: Scenario A to T* with RK45 on the GPU vs the reference's HDF5 golden, at the
+    reference's own tolerance (tests/Regression_test/test_regression.py:21-53)."""
+    from dataclasses import asdict, replace
+    from marlpde_amd.Evolve_scenario import integrate_equations
+    from marlpde_amd.parameters import Solver, Tracker
+    gold = np.load(f"{GOLDEN}/ref_final_scenarioA_Phi0_0.6_PhiIni_0.5.npy")
+    last, covered, depths, Xstar, folder = integrate_equations(
+        asdict(replace(Solver(), method="RK45")), asdict(Tracker()), scenario("A"), results_root=None, verbose=False)
+    assert last.shape == (5, 200) and covered == pytest.approx(13190.0) and folder is None and Xstar == 1319.0
+    np.testing.assert_allclose(last, gold, rtol=0.1, atol=0.01)
+    print("max abs deviation from the reference golden per field:", np.max(np.abs(last - gold), axis=1))
