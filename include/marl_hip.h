@@ -74,6 +74,10 @@ int marl_events_dev(marl_ctx* ctx, const double* y_dev, int layout, double* out)
 
 int marl_convert_layout_dev(marl_ctx* ctx, const double* src_dev, double* dst_dev, int src_layout, int dst_layout);
 
+/* Test hook: y[i] = op(x[i]) with the kernels' own math primitives: op 0 log, 1 exp, 2 pow(x, e),
+ * 3 reciprocal, 4 Fiadeiro-Veronis sigma(Pe = x, W = e).  Device pointers; asynchronous. */
+int marl_debug_math(marl_ctx* ctx, int op, const double* x_dev, double* y_dev, int64_t n, double e);
+
 /* ---- fixed-step classical RK4 (BASELINE config 2; no counterpart in the reference, which only
  * remarks that forward Euler fails: README.md:9).  y is advanced in place by nsteps steps of dt. */
 int marl_integrate_rk4(marl_ctx* ctx, double* y, double dt, int64_t nsteps);

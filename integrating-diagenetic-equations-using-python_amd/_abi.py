@@ -57,6 +57,7 @@ PROTOTYPES = {
     "marl_events": (_I, [_P, _P, _P]),
     "marl_events_dev": (_I, [_P, _P, _I, _P]),
     "marl_convert_layout_dev": (_I, [_P, _P, _P, _I, _I]),
+    "marl_debug_math": (_I, [_P, _I, _P, _P, _L, _D]),
     "marl_integrate_rk4": (_I, [_P, _P, _D, _L]),
     "marl_integrate_rk4_dev": (_I, [_P, _P, _I, _D, _L]),
     "marl_sweep_rk4_dev": (_I, [_P, _P, _P, _L]),

@@ -79,31 +79,31 @@ static void derive_consts(const marl_params& p, int64_t N, DevConsts& c, double 
     const double rhorat0 = (p.rhos0 / p.rhow - 1) * p.beta / p.sedimentationrate;
     const double F_fixed = 1 - std::exp(10 - 10 / p.PhiIni);
     memset(&c, 0, sizeof c);
-    c.inv_dx = 1.0 / dx;
-    c.inv_dx2 = std::pow(dx, -2);
-    c.dCa = dCa;
-    c.dCO3 = dCO3;
-    c.dPhi = auxcon * F_fixed * std::pow(p.PhiIni, 3) / (1 - p.PhiIni);
-    c.pe_cCa = delta_x / (2. * dCa);
-    c.pe_cCO3 = delta_x / (2. * dCO3);
-    c.pe_Phi = delta_x / (2. * c.dPhi);
-    c.presum = 1 - rhorat0 * std::pow(p.Phi0, 3) * (1 - std::exp(10 - 10 / p.Phi0)) / (1 - p.Phi0);
-    c.rhorat = (p.rhos / p.rhow - 1) * p.beta / p.sedimentationrate;
-    c.KRat = p.KC / p.KA;
-    c.nu1 = p.k1 / p.k2;
-    c.nu2 = p.k4 / p.k3;
-    c.m1 = p.m1; c.m2 = p.m2; c.n1 = p.n1; c.n2 = p.n2;
+    HotConsts& k = c.hot;
+    k.inv_dx = 1.0 / dx;
+    k.inv_dx2 = std::pow(dx, -2);
+    k.dCa = dCa;
+    k.dCO3 = dCO3;
+    k.dPhi = auxcon * F_fixed * std::pow(p.PhiIni, 3) / (1 - p.PhiIni);
+    k.pe_cCa = delta_x / (2. * dCa);
+    k.pe_cCO3 = delta_x / (2. * dCO3);
+    k.pe_Phi = delta_x / (2. * k.dPhi);
+    k.presum = 1 - rhorat0 * std::pow(p.Phi0, 3) * (1 - std::exp(10 - 10 / p.Phi0)) / (1 - p.Phi0);
+    k.rhorat = (p.rhos / p.rhow - 1) * p.beta / p.sedimentationrate;
+    k.KRat = p.KC / p.KA;
+    k.nu1 = p.k1 / p.k2;
+    k.nu2 = p.k4 / p.k3;
+    k.m1 = p.m1; k.m2 = p.m2; k.n1 = p.n1; k.n2 = p.n2;
     c.p0_m1 = std::pow(0.0, p.m1); c.p0_m2 = std::pow(0.0, p.m2);
     c.p0_n1 = std::pow(0.0, p.n1); c.p0_n2 = std::pow(0.0, p.n2);
-    c.lambda_ = p.k3 / p.k2;
-    c.Da = p.k2 * p.Tstar;
-    c.delta = p.rhos / (p.muA * std::sqrt(p.KC));
+    k.generic_p0 = (c.p0_m1 != 0 || c.p0_m2 != 0 || c.p0_n1 != 0 || c.p0_n2 != 0) ? 1 : 0;
+    k.lambda_ = p.k3 / p.k2;
+    k.Da = p.k2 * p.Tstar;
+    k.delta = p.rhos / (p.muA * std::sqrt(p.KC));
     const double bc[NF] = {p.CA0, p.CC0, p.cCa0, p.cCO30, p.Phi0};
     for (int f = 0; f < NF; f++) c.bc[f] = bc[f];
-    c.pe_min = 1e-2;
-    c.pe_max = 1 / c.pe_min;
     c.N = N;
-    c.fv = p.FV_switch;
+    k.fv = p.FV_switch;
     // mask = H(x - shallow) * H(deep - x) with H(0) = 0 at the cell centres: a contiguous index range
     int64_t lo = N, hi = N;
     bool open = false;
@@ -240,10 +240,11 @@ int marl_set_option(marl_ctx* ctx, const char* name, int64_t value)
 int marl_get_constants(const marl_ctx* ctx, int64_t inst, double out[19])
 {
     if (!ctx || inst < 0 || inst >= ctx->batch || !out) return -1;
-    const DevConsts& c = ctx->hconsts[inst];
+    const DevConsts& d = ctx->hconsts[inst];
+    const HotConsts& c = d.hot;
     const double* x = &ctx->extra[4 * inst];
     const double v[19] = {x[0], c.nu1, c.nu2, c.KRat, c.dCa, c.dCO3, c.delta, c.Da, c.lambda_, x[1], x[2], c.rhorat,
-                          c.presum, x[3], c.dPhi, c.pe_min, c.pe_max, (double)c.mask_lo, (double)c.mask_hi};
+                          c.presum, x[3], c.dPhi, PECLET_MIN, PECLET_MAX, (double)d.mask_lo, (double)d.mask_hi};
     memcpy(out, v, sizeof v);
     return 0;
 }
@@ -698,6 +699,16 @@ int marl_events(marl_ctx* ctx, const double* y, double* out)
     if (int rc = ensure(ctx, 0, n)) return rc;
     HIP_OK(ctx, hipMemcpyAsync(ctx->buf[0], y, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     return marl_events_dev(ctx, ctx->buf[0], LAYOUT_FIELD_MAJOR, out);
+}
+
+int marl_debug_math(marl_ctx* ctx, int op, const double* x_dev, double* y_dev, int64_t n, double e)
+{
+    if (!ctx || !x_dev || !y_dev || n < 0) return ctx ? fail(ctx, -1, "marl_debug_math: invalid argument") : -1;
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(math_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, op, x_dev, y_dev, n, e);
+    LAUNCH_OK(ctx);
+    return 0;
 }
 
 int marl_convert_layout_dev(marl_ctx* ctx, const double* src_dev, double* dst_dev, int src_layout, int dst_layout)

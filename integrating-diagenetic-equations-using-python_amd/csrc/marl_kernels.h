@@ -53,18 +53,36 @@ template <int BLK, int CPT>
 struct StencilBlock {
     static constexpr int WIN = BLK * CPT;
     static constexpr int NSIDE = (CPT == 1) ? 1 : 2;
-    static constexpr int LDS_DOUBLES = 2 * NSIDE * NF * BLK;  // [parity][side][field][thread]
+    static constexpr int LDS_DOUBLES = 2 * NSIDE * NF * BLK + TABLE_DOUBLES;  // edges [parity][side][field][thread] + tables
+
+    static constexpr int EDGE_DOUBLES = 2 * NSIDE * NF * BLK;
 
     double* lds;
+    Tables T;
+    HotConsts K;                 // hot constants, in registers for the whole kernel
+    const DevConsts* C;          // full constant block (cold members are read on rare paths only)
     int tid;
     int parity;
-    int64_t g0;  // global index of this thread's first cell
+    unsigned first_mask, last_mask, zone_mask;  // bit c: the thread's c-th cell is global cell 0 / N-1 / in the dissolution zone
 
-    __device__ __forceinline__ StencilBlock(double* lds_, int64_t g0_) : lds(lds_), tid(threadIdx.x), parity(0), g0(g0_) {}
+    // lds: LDS_DOUBLES doubles = edge exchange buffers followed by the log/exp tables (copied here; barrier inside).
+    // g0: global index of this thread's first cell.
+    __device__ __forceinline__ StencilBlock(double* lds_, int64_t g0, const DevConsts* __restrict__ c)
+        : lds(lds_), T(load_tables(lds_ + EDGE_DOUBLES, BLK)), K(load_hot(c)), C(c), tid(threadIdx.x), parity(0)
+    {
+        const int64_t N = c->N, mlo = c->mask_lo, mhi = c->mask_hi;
+        first_mask = last_mask = zone_mask = 0;
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            const int64_t g = g0 + i;
+            first_mask |= (g == 0) ? (1u << i) : 0u;
+            last_mask |= (g == N - 1) ? (1u << i) : 0u;
+            zone_mask |= (g >= mlo && g < mhi) ? (1u << i) : 0u;
+        }
+    }
 
     // k[c] = RHS(stage state ys) for the thread's CPT cells.  Contains exactly one __syncthreads().
-    __device__ __forceinline__ void eval(const double (&ys)[CPT][NF], double (&k)[CPT][NF], PointAux (&aux)[CPT],
-                                         const DevConsts& C)
+    __device__ __forceinline__ void eval(const double (&ys)[CPT][NF], double (&k)[CPT][NF], PointAux (&aux)[CPT])
     {
         double* e = lds + parity * (NSIDE * NF * BLK);
 #pragma unroll
@@ -84,22 +102,21 @@ struct StencilBlock {
         parity ^= 1;
 #pragma unroll
         for (int c = 0; c < CPT; c++) {
-            const int64_t g = g0 + c;
             double um[NF], up[NF];
 #pragma unroll
             for (int f = 0; f < NF; f++) {
                 um[f] = (c == 0) ? left[f] : ys[c > 0 ? c - 1 : 0][f];
                 up[f] = (c == CPT - 1) ? right[f] : ys[c < CPT - 1 ? c + 1 : c][f];
             }
-            if (g == C.N - 1) {
+            if (last_mask & (1u << c)) {
 #pragma unroll
                 for (int f = 0; f < NF; f++) up[f] = ghost_upper(f, ys[c][f], um[f]);
             }
-            if (g == 0) {
+            if (first_mask & (1u << c)) {
 #pragma unroll
-                for (int f = 0; f < NF; f++) um[f] = ghost_lower(C.bc[f], ys[c][f]);
+                for (int f = 0; f < NF; f++) um[f] = ghost_lower(C->bc[f], ys[c][f]);
             }
-            rhs_point(ys[c], um, up, g >= C.mask_lo && g < C.mask_hi, C, k[c], aux[c]);
+            rhs_point(ys[c], um, up, (zone_mask >> c) & 1u, K, C, T, k[c], aux[c]);
         }
     }
 };
@@ -148,6 +165,8 @@ template <int LAYOUT>
 __global__ void __launch_bounds__(256) rhs_kernel(const double* __restrict__ y, double* __restrict__ dydt,
                                                   const DevConsts* __restrict__ consts, Slab S, int64_t inst_stride)
 {
+    __shared__ double tabs[TABLE_DOUBLES];
+    const Tables T = load_tables(tabs, 256);
     const DevConsts& C = consts[blockIdx.y];
     y += blockIdx.y * inst_stride;
     dydt += blockIdx.y * inst_stride;
@@ -163,9 +182,29 @@ __global__ void __launch_bounds__(256) rhs_kernel(const double* __restrict__ y, 
     }
 #pragma unroll
     for (int f = 0; f < NF; f++) up[f] = (g < C.N - 1) ? y[at<LAYOUT>(f, l + 1, S.ld)] : ghost_upper(f, uc[f], um[f]);
-    rhs_point(uc, um, up, g >= C.mask_lo && g < C.mask_hi, C, r, aux);
+    const HotConsts K = load_hot(&C);
+    rhs_point(uc, um, up, g >= C.mask_lo && g < C.mask_hi, K, &C, T, r, aux);
 #pragma unroll
     for (int f = 0; f < NF; f++) dydt[at<LAYOUT>(f, l, S.ld)] = r[f];
+}
+
+// Element-wise evaluation of the device math primitives (accuracy tests only; marl_debug_math).
+__global__ void __launch_bounds__(256) math_probe_kernel(int op, const double* __restrict__ x, double* __restrict__ y, int64_t n, double e)
+{
+    __shared__ double tabs[TABLE_DOUBLES];
+    const Tables T = load_tables(tabs, 256);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double v = x[i];
+    double r;
+    switch (op) {
+        case 0: r = fast_log(v, T); break;
+        case 1: r = fast_exp(v, T); break;
+        case 2: r = pow_sat(v, e, T); break;
+        case 3: r = rcp_nr(v); break;
+        default: r = fv_sigma(v, e, T); break;
+    }
+    y[i] = r;
 }
 
 // Layout conversion FIELD_MAJOR <-> TILED (entry / exit of the fused integrators only).
@@ -211,6 +250,8 @@ __global__ void __launch_bounds__(256) monitors_kernel(const double* __restrict_
                                                        Slab S, int64_t inst_stride, double* __restrict__ part)
 {
     __shared__ double scratch[NQ * 4];
+    __shared__ double tabs[TABLE_DOUBLES];
+    const Tables T = load_tables(tabs, 256);
     const DevConsts& C = consts[blockIdx.y];
     y += blockIdx.y * inst_stride;
     double q[NQ];
@@ -220,9 +261,9 @@ __global__ void __launch_bounds__(256) monitors_kernel(const double* __restrict_
 #pragma unroll
         for (int f = 0; f < NF; f++) u[f] = y[at<LAYOUT>(f, l, S.ld)];
         const double Phi = u[4];
-        const double F = 1.0 - exp(10.0 - 10.0 * rcp_nr(Phi));
-        const double rF = C.rhorat * F;
-        monitors_accumulate(q, u, C.presum + rF * (Phi * Phi * Phi) * rcp_nr(1.0 - Phi), C.presum - rF * Phi * Phi);
+        const double F = 1.0 - fast_exp(10.0 - 10.0 * rcp_nr(Phi), T);
+        const double rF = C.hot.rhorat * F;
+        monitors_accumulate(q, u, C.hot.presum + rF * (Phi * Phi * Phi) * rcp_nr(1.0 - Phi), C.hot.presum - rF * Phi * Phi);
     }
     block_reduce<256, NQ, NQMIN>(q, scratch);
     if (threadIdx.x == 0) {
@@ -287,7 +328,7 @@ __global__ void __launch_bounds__(BLK) rk4_fused_kernel(const double* __restrict
 
     const int64_t w0 = S.out_lo + (int64_t)blockIdx.x * V - H;  // window start, local index
     const int64_t l0 = w0 + (int64_t)threadIdx.x * CPT;
-    StencilBlock<BLK, CPT> sb(lds, l0 + S.goff);
+    StencilBlock<BLK, CPT> sb(lds, l0 + S.goff, consts);
 
     double y[CPT][NF], ys[CPT][NF], k[CPT][NF], acc[CPT][NF];
     PointAux aux[CPT];
@@ -296,22 +337,22 @@ __global__ void __launch_bounds__(BLK) rk4_fused_kernel(const double* __restrict
 
 #pragma unroll 1
     for (int step = 0; step < NSTEPS; step++) {
-        sb.eval(y, k, aux, C);
+        sb.eval(y, k, aux);
 #pragma unroll
         for (int c = 0; c < CPT; c++)
 #pragma unroll
             for (int f = 0; f < NF; f++) { acc[c][f] = k[c][f]; ys[c][f] = y[c][f] + h2 * k[c][f]; }
-        sb.eval(ys, k, aux, C);
+        sb.eval(ys, k, aux);
 #pragma unroll
         for (int c = 0; c < CPT; c++)
 #pragma unroll
             for (int f = 0; f < NF; f++) { acc[c][f] = acc[c][f] + 2.0 * k[c][f]; ys[c][f] = y[c][f] + h2 * k[c][f]; }
-        sb.eval(ys, k, aux, C);
+        sb.eval(ys, k, aux);
 #pragma unroll
         for (int c = 0; c < CPT; c++)
 #pragma unroll
             for (int f = 0; f < NF; f++) { acc[c][f] = acc[c][f] + 2.0 * k[c][f]; ys[c][f] = y[c][f] + dt * k[c][f]; }
-        sb.eval(ys, k, aux, C);
+        sb.eval(ys, k, aux);
 #pragma unroll
         for (int c = 0; c < CPT; c++)
 #pragma unroll
@@ -501,7 +542,7 @@ __global__ void __launch_bounds__(256) rk45_control_kernel(const double* __restr
 struct DenseWeights { double w[7]; };
 
 template <int BLK, int CPT, bool DENSE = false>
-__device__ __forceinline__ void dp45_attempt(StencilBlock<BLK, CPT>& sb, const DevConsts& C, double h,
+__device__ __forceinline__ void dp45_attempt(StencilBlock<BLK, CPT>& sb, double h,
                                              const double (&y)[CPT][NF], const double (&k1)[CPT][NF],
                                              double (&yn)[CPT][NF], double (&k7)[CPT][NF], double (&esum)[CPT][NF],
                                              PointAux (&aux)[CPT], const DenseWeights& dw = DenseWeights{})
@@ -511,20 +552,20 @@ __device__ __forceinline__ void dp45_attempt(StencilBlock<BLK, CPT>& sb, const D
     double ys[CPT][NF], k2[CPT][NF], k3[CPT][NF], k4[CPT][NF], k5[CPT][NF], k6[CPT][NF];
 #define MARL_CELLS _Pragma("unroll") for (int c = 0; c < CPT; c++) _Pragma("unroll") for (int f = 0; f < NF; f++)
     MARL_CELLS ys[c][f] = y[c][f] + (k1[c][f] * dp::A21) * h;
-    sb.eval(ys, k2, aux, C);
+    sb.eval(ys, k2, aux);
     MARL_CELLS ys[c][f] = y[c][f] + (k1[c][f] * dp::A31 + k2[c][f] * dp::A32) * h;
-    sb.eval(ys, k3, aux, C);
+    sb.eval(ys, k3, aux);
     MARL_CELLS ys[c][f] = y[c][f] + (k1[c][f] * dp::A41 + k2[c][f] * dp::A42 + k3[c][f] * dp::A43) * h;
-    sb.eval(ys, k4, aux, C);
+    sb.eval(ys, k4, aux);
     MARL_CELLS ys[c][f] = y[c][f] + (k1[c][f] * dp::A51 + k2[c][f] * dp::A52 + k3[c][f] * dp::A53 + k4[c][f] * dp::A54) * h;
-    sb.eval(ys, k5, aux, C);
+    sb.eval(ys, k5, aux);
     MARL_CELLS ys[c][f] = y[c][f] + (k1[c][f] * dp::A61 + k2[c][f] * dp::A62 + k3[c][f] * dp::A63 + k4[c][f] * dp::A64 + k5[c][f] * dp::A65) * h;
-    sb.eval(ys, k6, aux, C);
+    sb.eval(ys, k6, aux);
     MARL_CELLS {
         yn[c][f] = y[c][f] + h * (k1[c][f] * dp::B1 + k3[c][f] * dp::B3 + k4[c][f] * dp::B4 + k5[c][f] * dp::B5 + k6[c][f] * dp::B6);
         esum[c][f] = k1[c][f] * e1 + k3[c][f] * e3 + k4[c][f] * e4 + k5[c][f] * e5 + k6[c][f] * e6;
     }
-    sb.eval(yn, k7, aux, C);
+    sb.eval(yn, k7, aux);
     MARL_CELLS esum[c][f] = esum[c][f] + k7[c][f] * e7;
 #undef MARL_CELLS
 }
@@ -564,7 +605,7 @@ __global__ void __launch_bounds__(BLK) rk45_attempt_kernel(double* __restrict__ 
 
     const int64_t w0 = S.out_lo + (int64_t)blockIdx.x * V - H;
     const int64_t l0 = w0 + (int64_t)threadIdx.x * CPT;
-    StencilBlock<BLK, CPT> sb(lds, l0 + S.goff);
+    StencilBlock<BLK, CPT> sb(lds, l0 + S.goff, consts);
 
     double y[CPT][NF], k1[CPT][NF], yn[CPT][NF], k7[CPT][NF], esum[CPT][NF];
     PointAux aux[CPT];
@@ -576,7 +617,7 @@ __global__ void __launch_bounds__(BLK) rk45_attempt_kernel(double* __restrict__ 
 #pragma unroll
         for (int f = 0; f < NF; f++) k1[c][f] = in ? fin[at<LAYOUT>(f, l, S.ld)] : 0.0;
     }
-    dp45_attempt<BLK, CPT>(sb, C, h, y, k1, yn, k7, esum, aux);
+    dp45_attempt<BLK, CPT>(sb, h, y, k1, yn, k7, esum, aux);
 
     double q[NQ];
     monitors_init(q);
@@ -602,12 +643,12 @@ __global__ void __launch_bounds__(BLK) rk45_attempt_kernel(double* __restrict__ 
 }
 
 // U and W of a state (monitors zeros_U / zeros_W, LHeureux_model.py:567-593)
-__device__ __forceinline__ void uw_point(double Phi, const DevConsts& C, double& U, double& W)
+__device__ __forceinline__ void uw_point(double Phi, const DevConsts& C, const Tables& T, double& U, double& W)
 {
-    const double F = 1.0 - exp(10.0 - 10.0 * rcp_nr(Phi));
-    const double rF = C.rhorat * F;
-    U = C.presum + rF * (Phi * Phi * Phi) * rcp_nr(1.0 - Phi);
-    W = C.presum - rF * Phi * Phi;
+    const double F = 1.0 - fast_exp(10.0 - 10.0 * rcp_nr(Phi), T);
+    const double rF = C.hot.rhorat * F;
+    U = C.hot.presum + rF * (Phi * Phi * Phi) * rcp_nr(1.0 - Phi);
+    W = C.hot.presum - rF * Phi * Phi;
 }
 
 // Dense output of the step that starts at (yold, fold) with size h: replays the step's stages and
@@ -625,7 +666,7 @@ __global__ void __launch_bounds__(BLK) rk45_dense_kernel(const double* __restric
     const DevConsts& C = consts[0];
     const int64_t w0 = S.out_lo + (int64_t)blockIdx.x * V - H;
     const int64_t l0 = w0 + (int64_t)threadIdx.x * CPT;
-    StencilBlock<BLK, CPT> sb(lds, l0 + S.goff);
+    StencilBlock<BLK, CPT> sb(lds, l0 + S.goff, consts);
     double y[CPT][NF], k1[CPT][NF], yn[CPT][NF], k7[CPT][NF], dsum[CPT][NF];
     PointAux aux[CPT];
     load_cells<CPT, LAYOUT>(yold, l0, S, C, y);
@@ -636,7 +677,7 @@ __global__ void __launch_bounds__(BLK) rk45_dense_kernel(const double* __restric
 #pragma unroll
         for (int f = 0; f < NF; f++) k1[c][f] = in ? fold[at<LAYOUT>(f, l, S.ld)] : 0.0;
     }
-    dp45_attempt<BLK, CPT, true>(sb, C, h, y, k1, yn, k7, dsum, aux, dw);
+    dp45_attempt<BLK, CPT, true>(sb, h, y, k1, yn, k7, dsum, aux, dw);
     double q[NQ];
     monitors_init(q);
 #pragma unroll
@@ -651,7 +692,7 @@ __global__ void __launch_bounds__(BLK) rk45_dense_kernel(const double* __restric
                 if (yout) yout[at<LAYOUT>(f, l, S.ld)] = d[f];
             }
             double U, W;
-            uw_point(d[4], C, U, W);
+            uw_point(d[4], C, sb.T, U, W);
             monitors_accumulate(q, d, U, W);
         }
     }
@@ -679,7 +720,7 @@ __global__ void __launch_bounds__(BLK) rk45_sweep_kernel(double* __restrict__ Y,
     double* yg = Y + (int64_t)blockIdx.x * NF * N;
     Slab S = {N, 0, N, 0, N};
     const int64_t l0 = (int64_t)threadIdx.x * CPT;
-    StencilBlock<BLK, CPT> sb(lds, l0);
+    StencilBlock<BLK, CPT> sb(lds, l0, consts + blockIdx.x);
     if (threadIdx.x == 0) sc = ctrls[blockIdx.x];
     __syncthreads();
     if (sc.status != ST_RUNNING) return;
@@ -688,11 +729,11 @@ __global__ void __launch_bounds__(BLK) rk45_sweep_kernel(double* __restrict__ Y,
     double y[CPT][NF], k1[CPT][NF], yn[CPT][NF], k7[CPT][NF], esum[CPT][NF];
     PointAux aux[CPT];
     load_cells<CPT, LAYOUT_FIELD_MAJOR>(yg, l0, S, C, y);
-    sb.eval(y, k1, aux, C);  // f(t, y): RungeKutta.__init__ (first launch) or re-derived on resume
+    sb.eval(y, k1, aux);  // f(t, y): RungeKutta.__init__ (first launch) or re-derived on resume
 
     while (true) {
         const double h = sc.h_try;
-        dp45_attempt<BLK, CPT>(sb, C, h, y, k1, yn, k7, esum, aux);
+        dp45_attempt<BLK, CPT>(sb, h, y, k1, yn, k7, esum, aux);
         double q[NQ];
         monitors_init(q);
 #pragma unroll
@@ -751,7 +792,7 @@ __global__ void __launch_bounds__(BLK) rk4_sweep_kernel(double* __restrict__ Y, 
     double* yg = Y + (int64_t)blockIdx.x * NF * N;
     Slab S = {N, 0, N, 0, N};
     const int64_t l0 = (int64_t)threadIdx.x * CPT;
-    StencilBlock<BLK, CPT> sb(lds, l0);
+    StencilBlock<BLK, CPT> sb(lds, l0, consts + blockIdx.x);
     const double dt = dts[blockIdx.x];
     const double h2 = 0.5 * dt, h6 = dt / 6.0;
     double y[CPT][NF], ys[CPT][NF], k[CPT][NF], acc[CPT][NF];
@@ -760,13 +801,13 @@ __global__ void __launch_bounds__(BLK) rk4_sweep_kernel(double* __restrict__ Y, 
 #define MARL_CELLS _Pragma("unroll") for (int c = 0; c < CPT; c++) _Pragma("unroll") for (int f = 0; f < NF; f++)
 #pragma unroll 1
     for (int64_t s = 0; s < nsteps; s++) {
-        sb.eval(y, k, aux, C);
+        sb.eval(y, k, aux);
         MARL_CELLS { acc[c][f] = k[c][f]; ys[c][f] = y[c][f] + h2 * k[c][f]; }
-        sb.eval(ys, k, aux, C);
+        sb.eval(ys, k, aux);
         MARL_CELLS { acc[c][f] = acc[c][f] + 2.0 * k[c][f]; ys[c][f] = y[c][f] + h2 * k[c][f]; }
-        sb.eval(ys, k, aux, C);
+        sb.eval(ys, k, aux);
         MARL_CELLS { acc[c][f] = acc[c][f] + 2.0 * k[c][f]; ys[c][f] = y[c][f] + dt * k[c][f]; }
-        sb.eval(ys, k, aux, C);
+        sb.eval(ys, k, aux);
         MARL_CELLS y[c][f] = y[c][f] + h6 * (acc[c][f] + k[c][f]);
     }
 #undef MARL_CELLS
