@@ -100,6 +100,10 @@ static void derive_consts(const marl_params& p, int64_t N, DevConsts& c, double 
     k.lambda_ = p.k3 / p.k2;
     k.Da = p.k2 * p.Tstar;
     k.delta = p.rhos / (p.muA * std::sqrt(p.KC));
+    k.hdx = 0.5 * k.inv_dx;
+    k.pe_smax = k.pe_cCa > k.pe_cCO3 ? k.pe_cCa : k.pe_cCO3;
+    k.Dal = k.Da * k.lambda_;
+    k.rr10 = 10.0 * k.rhorat;
     const double bc[NF] = {p.CA0, p.CC0, p.cCa0, p.cCO30, p.Phi0};
     for (int f = 0; f < NF; f++) c.bc[f] = bc[f];
     c.N = N;

@@ -108,13 +108,16 @@ struct StencilBlock {
                 um[f] = (c == 0) ? left[f] : ys[c > 0 ? c - 1 : 0][f];
                 up[f] = (c == CPT - 1) ? right[f] : ys[c < CPT - 1 ? c + 1 : c][f];
             }
-            if (last_mask & (1u << c)) {
+            // physical boundaries: two cells of the whole grid - a wave-uniform branch, skipped by every other wave
+            if (__builtin_amdgcn_ballot_w64(((first_mask | last_mask) >> c) & 1u) != 0) {
+                if (last_mask & (1u << c)) {
 #pragma unroll
-                for (int f = 0; f < NF; f++) up[f] = ghost_upper(f, ys[c][f], um[f]);
-            }
-            if (first_mask & (1u << c)) {
+                    for (int f = 0; f < NF; f++) up[f] = ghost_upper(f, ys[c][f], um[f]);
+                }
+                if (first_mask & (1u << c)) {
 #pragma unroll
-                for (int f = 0; f < NF; f++) um[f] = ghost_lower(C->bc[f], ys[c][f]);
+                    for (int f = 0; f < NF; f++) um[f] = ghost_lower(C->bc[f], ys[c][f]);
+                }
             }
             rhs_point(ys[c], um, up, (zone_mask >> c) & 1u, K, C, T, k[c], aux[c]);
         }

@@ -40,6 +40,10 @@ struct HotConsts {
     double dCa, dCO3, dPhi;          // :60, :61, :132-133 (dPhi_fixed)
     double pe_cCa, pe_cCO3, pe_Phi;  // delta_x/(2 dCa), delta_x/(2 dCO3), delta_x/(2 dPhi_fixed)  (:436,444,452)
     double m1, m2, n1, n2;           // kinetics exponents
+    double hdx;                      // 0.5/dx
+    double pe_smax;                  // max(pe_cCa, pe_cCO3)
+    double Dal;                      // Da * lambda_
+    double rr10;                     // 10 * rhorat
     int32_t fv;                      // FV_switch
     int32_t generic_p0;              // some exponent <= 0, i.e. some pow(0, e) != 0: take the general combination
 };
@@ -75,14 +79,13 @@ __device__ __forceinline__ HotConsts load_hot(const DevConsts* __restrict__ c)
 
 __device__ __forceinline__ double rcp_nr(double x)
 {
-    // v_rcp_f64 seed + two Newton-Raphson steps: <= 1 ulp for normal x; x = 0 -> inf, inf -> 0, NaN -> NaN
+    // v_rcp_f64 seed + two Newton-Raphson steps: <= 1 ulp for finite non-zero x.  x = 0 or inf gives NaN
+    // (the correction computes 0 * inf); every caller's result is non-finite in the reference too there.
     const double r0 = __builtin_amdgcn_rcp(x);
     double e = __builtin_fma(-x, r0, 1.0);
     const double r1 = __builtin_fma(r0, e, r0);
     e = __builtin_fma(-x, r1, 1.0);
-    const double r2 = __builtin_fma(r1, e, r1);
-    // keep the seed's inf/0 (the correction turns them into NaN); a NaN seed stays NaN
-    return (r2 == r2) ? r2 : r0;
+    return __builtin_fma(r1, e, r1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -117,41 +120,35 @@ __device__ __forceinline__ double fast_log(double x, const Tables& T)
     const double z = __hiloint2double((int)(hi - ((uint32_t)t & 0xfff00000u)), (int)lo);
     const double invc = T.log_tab[2 * i], logc = T.log_tab[2 * i + 1];
     const double r = __builtin_fma(z, invc, -1.0);
-    const double kd = (double)k;
-    const double w = __builtin_fma(kd, tab::LN2_HI, logc);
-    const double hi_ = w + r;
-    const double lo_ = (w - hi_) + r + kd * tab::LN2_LO;
     const double r2 = r * r;
     // log1p(r) - r = r^2 (-1/2 + r/3 - r^2/4 + r^3/5 - r^4/6),  |r| < 2^-8: truncation < 2e-18
     const double p = __builtin_fma(r, 1.0 / 3, -0.5) + r2 * (__builtin_fma(r, 1.0 / 5, -0.25) + r2 * (-1.0 / 6));
-    return __builtin_fma(r2, p, lo_) + hi_;
+    return __builtin_fma((double)k, tab::LN2, logc) + __builtin_fma(r2, p, r);
 }
 
 __device__ __forceinline__ double fast_exp(double x, const Tables& T)
 {
-    // exp x = 2^k 2^(i/128) e^r,  x = (128 k + i) ln2/128 + r,  |r| <= ln2/256.  Arguments are clamped to
-    // [-1000, 710] first (0 resp. inf come out of ldexp / the final scaling, gradual underflow too; the
-    // scale is applied as 2^(k-2) * 4 so that s itself never overflows before the fma); NaN is restored.
-    const double xc = fmin(fmax(x, -1000.0), 710.0);
-    const double kd = __builtin_rint(xc * tab::INV_LN2N);
+    // exp x = 2^k 2^(i/128) e^r,  x = (128 k + i) ln2/128 + r,  |r| <= ln2/256.  ldexp gives gradual
+    // underflow and 0 for very negative x (down to about -1e7); NaN stays NaN.  Not for x = -inf, x > 709.
+    const double kd = __builtin_rint(x * tab::INV_LN2N);
     const int ki = (int)kd;
-    double r = __builtin_fma(kd, -tab::LN2N_HI, xc);
+    double r = __builtin_fma(kd, -tab::LN2N_HI, x);
     r = __builtin_fma(kd, -tab::LN2N_LO, r);
-    const double s = ldexp(T.exp_tab[ki & (tab::N - 1)], (ki >> 7) - 2);
+    const double s = ldexp(T.exp_tab[ki & (tab::N - 1)], ki >> 7);
     const double r2 = r * r;
     // e^r - 1 = r + r^2 (1/2 + r/6) + r^4 (1/24 + r/120),  truncation r^6/720 < 6e-19
     const double tmp = r + r2 * __builtin_fma(r, 1.0 / 6, 0.5) + (r2 * r2) * __builtin_fma(r, 1.0 / 120, 1.0 / 24);
-    const double res = __builtin_fma(s, tmp, s) * 4.0;
-    return (x != x) ? x : res;
+    return __builtin_fma(s, tmp, s);
 }
 
 // pow(b, e) for b >= 0 (a clamped saturation distance) and a real kinetics exponent: exp(e log b).
 // Relative error ~ (2 + 2.5 |e ln b|) ulp: ~1e-15 for b > 1e-3; for smaller b the value b^e itself is
-// negligible against the O(1) terms it is added to.  b = 0 gives exp(-inf) = 0 for e > 0;
-// the general pow(0, e) is patched in by the caller when an exponent is <= 0.
+// negligible against the O(1) terms it is added to.  b = 0 gives 0 (right for e > 0; the
+// general pow(0, e) is patched in by the caller when an exponent is <= 0).
 __device__ __forceinline__ double pow_sat(double b, double e, const Tables& T)
 {
-    return fast_exp(e * fast_log(b, T), T);
+    const double r = fast_exp(e * fast_log(b, T), T);
+    return (b == 0.0) ? 0.0 : r;
 }
 
 // Fiadeiro-Veronis weight sigma(Pe) for |Pe| >= PECLET_MIN; LHeureux_model.py:437-442 (= calculate_sigma :147-160)
@@ -188,87 +185,82 @@ __device__ __forceinline__ void rhs_point(const double (&uc)[NF], const double (
 
     // ---- porosity-only quantities: F, U, W, den (:414-429).  ONE reciprocal serves 1/Phi, 1/(1-Phi), 1/den.
     const double omPhi = 1.0 - Phi;
-    const double den = 1.0 - 2.0 * fast_log(Phi, T);
+    const double den = __builtin_fma(-2.0, fast_log(Phi, T), 1.0);
     const double pd = Phi * den, od = omPhi * den, po = Phi * omPhi;
     const double rall = rcp_nr(pd * omPhi);
     const double invPhi = rall * od, invom = rall * pd, invden = rall * po;
-    const double F = 1.0 - fast_exp(10.0 - 10.0 * invPhi, T);
-    const double Phi2 = Phi * Phi;
+    const double F = 1.0 - fast_exp(__builtin_fma(-10.0, invPhi, 10.0), T);
     const double rF = K.rhorat * F;
-    const double U = K.presum + rF * (Phi2 * Phi) * invom;
-    const double W = K.presum - rF * Phi2;
+    const double t2 = rF * (Phi * Phi);
+    const double W = K.presum - t2;
+    const double U = __builtin_fma(t2 * Phi, invom, K.presum);
     aux.U = U;
     aux.W = W;
 
-    // ---- upwinded solid gradients (:418-423)
-    const bool upw = U > 0.0;
-    const double CAg = (upw ? (CA - um[0]) : (up[0] - CA)) * K.inv_dx;
-    const double CCg = (upw ? (CC - um[1]) : (up[1] - CC)) * K.inv_dx;
-
-    // ---- Fiadeiro-Veronis weights (:433-462); all three vanish when every |Pe| < PECLET_MIN (fine grids)
-    double s_c = 0.0, s_o = 0.0, s_p = 0.0;
-    if (K.fv) {
-        const double Wd = W * den;
-        const double Pc = Wd * K.pe_cCa, Po = Wd * K.pe_cCO3, Pp = W * K.pe_Phi;
-        if (!(fmax(fmax(fabs(Pc), fabs(Po)), fabs(Pp)) < PECLET_MIN)) {
-            s_c = fv_sigma(Pc, W, T);
-            s_o = fv_sigma(Po, W, T);
-            s_p = fv_sigma(Pp, W, T);
-        }
-    }
-    // weighted gradients 0.5*((1-s) forw + (1+s) back) and Laplacians (:464-469, :372-384)
+    // ---- one-sided differences (x dx): back = u - u[i-1], forw = u[i+1] - u   (:372-384)
+    const double a_b = CA - um[0], a_f = up[0] - CA;
+    const double k_b = CC - um[1], k_f = up[1] - CC;
     const double c_b = c - um[2], c_f = up[2] - c;
     const double o_b = o - um[3], o_f = up[3] - o;
     const double p_b = Phi - um[4], p_f = up[4] - Phi;
-    const double hdx = 0.5 * K.inv_dx;
-    const double cg = ((1.0 - s_c) * c_f + (1.0 + s_c) * c_b) * hdx;
-    const double og = ((1.0 - s_o) * o_f + (1.0 + s_o) * o_b) * hdx;
-    const double pg = ((1.0 - s_p) * p_f + (1.0 + s_p) * p_b) * hdx;
-    const double c_lap = (c_f - c_b) * K.inv_dx2;
-    const double o_lap = (o_f - o_b) * K.inv_dx2;
-    const double p_lap = (p_f - p_b) * K.inv_dx2;
-
-    // ---- porosity-coupled diffusion helpers (:471-477)
-    const double h1 = Phi * invden;
-    const double h2 = pg * (2.0 + den) * (invden * invden);
-    const double Hc = K.dCa * (h2 * cg + h1 * c_lap);
-    const double Ho = K.dCO3 * (h2 * og + h1 * o_lap);
 
     // ---- reaction terms (:479-493).  Of each clamp pair (min(x,1), max(x,1)) one power has base exactly 0
-    // and the other is evaluated; with positive exponents (generic_p0 == 0) the zero-base member vanishes.
+    // and the other has base |x - 1|; with positive exponents the zero-base member vanishes.
     const double O2 = c * o;
     const double O3 = O2 * K.KRat;
     const bool under = O3 < 1.0;
     const bool over = O2 > 1.0;
-    double pwA = O3 - O3;  // 0, or NaN for a non-finite O3 (keeps the reference's NaN visible)
-    if (!under || in_mask) pwA = pow_sat(under ? 1.0 - O3 : O3 - 1.0, under ? K.m2 : K.m1, T);
-    const double pwC = pow_sat(over ? O2 - 1.0 : 1.0 - O2, over ? K.n1 : K.n2, T);
-    double tA, tC;
-    if (!K.generic_p0) {
-        tA = under ? pwA : -K.nu1 * pwA;   // (1-O3)^m2 * mask   |  -nu1 (O3-1)^m1
-        tC = over ? pwC : -K.nu2 * pwC;    // (O2-1)^n1          |  -nu2 (1-O2)^n2
-    } else {
+    const double pwC = pow_sat(fabs(O2 - 1.0), over ? K.n1 : K.n2, T);
+    double tC = (over ? 1.0 : -K.nu2) * pwC;   // (O2-1)^n1  |  -nu2 (1-O2)^n2
+    double tA = O3 - O3;                        // 0, or NaN for a non-finite O3 (keeps the reference's NaN visible)
+    if (!under || in_mask) {
+        const double pwA = pow_sat(fabs(O3 - 1.0), under ? K.m2 : K.m1, T);
+        tA = (under ? 1.0 : -K.nu1) * pwA;      // (1-O3)^m2 * mask  |  -nu1 (O3-1)^m1
+    }
+    if (K.generic_p0) {  // an exponent <= 0: pow(0, e) is 1 or inf instead of 0 (rare; constants from memory)
         const double z1 = C->p0_m1, z2 = C->p0_m2, y1 = C->p0_n1, y2 = C->p0_n2;
         const double mask = in_mask ? 1.0 : 0.0;
-        const double a_under = ((under ? 1.0 - O3 : 1.0) == 0.0) ? z2 : pwA;   // pow(0, m2) when O3 == 1 exactly
-        const double a_over = ((under ? 0.0 : O3 - 1.0) == 0.0) ? z1 : pwA;
-        tA = under ? (in_mask ? a_under : pwA) * mask - K.nu1 * z1 : z2 * mask - K.nu1 * a_over;
-        const double c_over = ((over ? O2 - 1.0 : 0.0) == 0.0) ? y1 : pwC;
-        const double c_under = ((over ? 1.0 : 1.0 - O2) == 0.0) ? y2 : pwC;
-        tC = over ? c_over - K.nu2 * y2 : y1 - K.nu2 * c_under;
+        const double pa = (O3 == 1.0) ? (under ? z2 : z1) : ((!under || in_mask) ? fast_exp((under ? K.m2 : K.m1) * fast_log(fabs(O3 - 1.0), T), T) : 0.0);
+        const double pc = (O2 == 1.0) ? (over ? y1 : y2) : pwC;
+        tA = under ? pa * mask - K.nu1 * z1 : z2 * mask - K.nu1 * pa;
+        tC = over ? pc - K.nu2 * y2 : y1 - K.nu2 * pc;
     }
-    const double coA = CA * tA;
-    const double coC = CC * tC;
-    const double R = coA - K.lambda_ * coC;
+    const double DA = K.Da * (CA * tA);          // Da coA
+    const double DC = K.Dal * (CC * tC);         // Da lambda coC
+    const double DaR = omPhi * (DA - DC);        // Da (1-Phi) (coA - lambda coC)
 
-    const double dWdx = -K.rhorat * pg * (2.0 * Phi * F + 10.0 * (F - 1.0));  // :495
-    const double DaR = K.Da * omPhi * R;
+    // ---- solids: upwinded gradient (:418-423) and rates (:498-503)
+    const bool upw = U > 0.0;
+    const double Ux = U * K.inv_dx;
+    r[0] = __builtin_fma(-Ux, upw ? a_b : a_f, -__builtin_fma(CA, DC, (1.0 - CA) * DA));
+    r[1] = __builtin_fma(-Ux, upw ? k_b : k_f, __builtin_fma(CC, DA, (1.0 - CC) * DC));
 
-    r[0] = -U * CAg - K.Da * ((1.0 - CA) * coA + K.lambda_ * CA * coC);           // :498-499
-    r[1] = -U * CCg + K.Da * (K.lambda_ * (1.0 - CC) * coC + CC * coA);           // :502-503
-    r[2] = (Hc + DaR * (K.delta - c)) * invPhi - W * cg;                          // :506-509
-    r[3] = (Ho + DaR * (K.delta - o)) * invPhi - W * og;                          // :512-515
-    r[4] = -(dWdx * Phi + W * pg) + K.dPhi * p_lap + DaR;                         // :518-520
+    // ---- solutes and porosity.  Fiadeiro-Veronis weights (:433-462) all vanish when every |Pe| < PECLET_MIN
+    // (always on fine grids): then the weighted gradient 0.5*((1-s) forw + (1+s) back) is the central one.
+    const double Wd = W * den;
+    const bool fv_active = K.fv && !(fabs(Wd) * K.pe_smax < PECLET_MIN && fabs(W) * K.pe_Phi < PECLET_MIN);
+    const double h1x = (Phi * invden) * K.inv_dx2;                  // Phi/den / dx^2
+    const double h2f = (2.0 + den) * (invden * invden);             // (2+den)/den^2
+    const double q = __builtin_fma(rF, __builtin_fma(2.0, Phi, 10.0), -K.rr10);  // rhorat (2 Phi F + 10 (F-1))  (:495)
+    const double p_d = p_f - p_b, c_d = c_f - c_b, o_d = o_f - o_b;
+    double pg, cg, og;  // gradients (already divided by dx)
+    if (!fv_active) {
+        pg = (p_f + p_b) * K.hdx;
+        cg = (c_f + c_b) * K.hdx;
+        og = (o_f + o_b) * K.hdx;
+    } else {
+        const double s_c = fv_sigma(Wd * K.pe_cCa, W, T), s_o = fv_sigma(Wd * K.pe_cCO3, W, T), s_p = fv_sigma(W * K.pe_Phi, W, T);
+        cg = ((1.0 - s_c) * c_f + (1.0 + s_c) * c_b) * K.hdx;
+        og = ((1.0 - s_o) * o_f + (1.0 + s_o) * o_b) * K.hdx;
+        pg = ((1.0 - s_p) * p_f + (1.0 + s_p) * p_b) * K.hdx;
+    }
+    const double h2 = pg * h2f;                                      // common_helper2 (:472-473)
+    const double Hc = K.dCa * __builtin_fma(h2, cg, h1x * c_d);      // (:474-475)
+    const double Ho = K.dCO3 * __builtin_fma(h2, og, h1x * o_d);     // (:476-477)
+    r[2] = __builtin_fma(-W, cg, __builtin_fma(DaR, K.delta - c, Hc) * invPhi);   // :506-509
+    r[3] = __builtin_fma(-W, og, __builtin_fma(DaR, K.delta - o, Ho) * invPhi);   // :512-515
+    // -(dWdx Phi + W Phi') with dWdx = -q Phi'  ->  -Phi' (W - Phi q)             // :495, :518-520
+    r[4] = __builtin_fma(-pg, __builtin_fma(-Phi, q, W), __builtin_fma(K.dPhi * K.inv_dx2, p_d, DaR));
 }
 
 }  // namespace marl
