@@ -257,6 +257,7 @@ int64_t marl_state_doubles(const marl_ctx* ctx, int layout) { return ctx ? state
 
 }  // extern "C"
 
+#ifndef MARL_LAB  // tools/rk4_lab.hip includes this file for context creation only
 // ----------------------------------------------------------------------------------------------
 // launch helpers
 // ----------------------------------------------------------------------------------------------
@@ -318,6 +319,7 @@ static void record_to_events(const double* r, double* g)
 struct Rk4Variant { int blk, cpt, nsteps; };
 static const Rk4Variant kRk4Variants[] = {
     {256, 1, 1}, {256, 1, 2}, {256, 2, 1}, {256, 2, 2}, {128, 1, 4}, {128, 1, 8}, {256, 2, 4}, {512, 1, 1}, {256, 4, 1}, {128, 1, 1},
+    {256, 1, 4}, {256, 1, 8},
 };
 constexpr int kNumRk4Variants = sizeof(kRk4Variants) / sizeof(kRk4Variants[0]);
 
@@ -340,6 +342,8 @@ static int launch_rk4(marl_ctx* ctx, int v, bool single, const double* yin, doub
     switch (key) {
         case 256101: launch_rk4_t<256, 1, 1>(ctx, yin, yout, layout, dt); break;
         case 256102: launch_rk4_t<256, 1, 2>(ctx, yin, yout, layout, dt); break;
+        case 256104: launch_rk4_t<256, 1, 4>(ctx, yin, yout, layout, dt); break;
+        case 256108: launch_rk4_t<256, 1, 8>(ctx, yin, yout, layout, dt); break;
         case 256201: launch_rk4_t<256, 2, 1>(ctx, yin, yout, layout, dt); break;
         case 256202: launch_rk4_t<256, 2, 2>(ctx, yin, yout, layout, dt); break;
         case 256204: launch_rk4_t<256, 2, 4>(ctx, yin, yout, layout, dt); break;
@@ -358,7 +362,7 @@ static int default_rk4_variant(const marl_ctx* ctx)
 {
     if (ctx->rk4_variant >= 0 && ctx->rk4_variant < kNumRk4Variants) return (int)ctx->rk4_variant;
     const int64_t n = ctx->slab.out_hi - ctx->slab.out_lo;
-    return n <= 131072 ? 5 : 2;  // small grids: deep temporal fusion (launch bound); large: 2 cells/thread
+    return n <= 131072 ? 5 : 10;  // small grids: 8 steps/launch on 128-thread blocks (launch bound); large: 4 steps/launch
 }
 
 // y (device, `layout`) advanced in place; `tmp` is a second buffer of the same size
@@ -394,7 +398,7 @@ static int default_sweep_variant(marl_ctx* ctx)
         const SweepVariant& sv = kSweepVariants[ctx->sweep_variant];
         if ((int64_t)sv.blk * sv.cpt >= ctx->N) return (int)ctx->sweep_variant;
     }
-    const int order[] = {3, 4, 5, 8, 6, 7, 0, 1, 2};  // smallest window first
+    const int order[] = {3, 4, 5, 8, 6, 7, 1, 0, 2};  // smallest window first; among equal windows the measured-fastest first
     int best = -1;
     int64_t best_win = 0;
     for (int i : order) {
@@ -844,3 +848,4 @@ int marl_integrate_rk45(marl_ctx* ctx, double* y, double t0, double t1, double f
 }
 
 }  // extern "C"
+#endif  // MARL_LAB

@@ -70,7 +70,13 @@ struct StencilBlock {
     __device__ __forceinline__ StencilBlock(double* lds_, int64_t g0, const DevConsts* __restrict__ c)
         : lds(lds_), T(load_tables(lds_ + EDGE_DOUBLES, BLK)), K(load_hot(c)), C(c), tid(threadIdx.x), parity(0)
     {
-        const int64_t N = c->N, mlo = c->mask_lo, mhi = c->mask_hi;
+        set_window(g0);
+    }
+
+    // (Re)position the window: persistent kernels walk one block over several windows.
+    __device__ __forceinline__ void set_window(int64_t g0)
+    {
+        const int64_t N = C->N, mlo = C->mask_lo, mhi = C->mask_hi;
         first_mask = last_mask = zone_mask = 0;
 #pragma unroll
         for (int i = 0; i < CPT; i++) {
@@ -318,10 +324,16 @@ __device__ __forceinline__ void load_cells(const double* __restrict__ y, int64_t
 //   k1 = f(y); k2 = f(y + dt/2 k1); k3 = f(y + dt/2 k2); k4 = f(y + dt k3)
 //   y <- y + dt/6 (((k1 + 2 k2) + 2 k3) + k4)                 (same order as oracle/marl_oracle.c)
 // ---------------------------------------------------------------------------------------------
+#ifdef MARL_LAB_CLOCK  // kernel-lab diagnostic build only: in-kernel shader clock (s_memtime) vs 100 MHz s_memrealtime
+__device__ unsigned long long marl_lab_clock[3 * 16384];
+#endif
 template <int BLK, int CPT, int LAYOUT, int NSTEPS>
 __global__ void __launch_bounds__(BLK) rk4_fused_kernel(const double* __restrict__ yin, double* __restrict__ yout,
                                                         const DevConsts* __restrict__ consts, Slab S, double dt)
 {
+#ifdef MARL_LAB_CLOCK
+    const unsigned long long lab_t0 = __builtin_amdgcn_s_memtime(), lab_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     constexpr int H = 4 * NSTEPS;
     constexpr int WIN = BLK * CPT;
     constexpr int V = WIN - 2 * H;
@@ -331,11 +343,10 @@ __global__ void __launch_bounds__(BLK) rk4_fused_kernel(const double* __restrict
 
     const int64_t w0 = S.out_lo + (int64_t)blockIdx.x * V - H;  // window start, local index
     const int64_t l0 = w0 + (int64_t)threadIdx.x * CPT;
-    StencilBlock<BLK, CPT> sb(lds, l0 + S.goff, consts);
-
     double y[CPT][NF], ys[CPT][NF], k[CPT][NF], acc[CPT][NF];
     PointAux aux[CPT];
-    load_cells<CPT, LAYOUT>(yin, l0, S, C, y);
+    load_cells<CPT, LAYOUT>(yin, l0, S, C, y);              // in flight while the tables are staged
+    StencilBlock<BLK, CPT> sb(lds, l0 + S.goff, consts);   // (table copy + barrier inside)
     const double h2 = 0.5 * dt, h6 = dt / 6.0;
 
 #pragma unroll 1
@@ -371,6 +382,80 @@ __global__ void __launch_bounds__(BLK) rk4_fused_kernel(const double* __restrict
             for (int f = 0; f < NF; f++) yout[at<LAYOUT>(f, l, S.ld)] = y[c][f];
         }
     }
+#ifdef MARL_LAB_CLOCK
+    if (threadIdx.x == 0 && blockIdx.x < 16384) {
+        marl_lab_clock[3 * blockIdx.x] = __builtin_amdgcn_s_memtime() - lab_t0;
+        marl_lab_clock[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - lab_r0;
+        marl_lab_clock[3 * blockIdx.x + 2] = lab_r0;
+    }
+#endif
+}
+
+// Persistent form of the fused RK4 kernel: a fixed grid of resident workgroups, each walking over windows
+// blockIdx.x, blockIdx.x + gridDim.x, ...  The NEXT window's state is loaded while the current one is being
+// integrated (software prefetch), so HBM traffic overlaps the fp64 work instead of alternating with it (in the
+// one-window-per-block form all blocks of a dispatch round load, compute and store in lock-step), and the
+// log/exp tables and constants are set up once per block instead of once per window.
+#ifndef MARL_PERSIST_WAVES
+#define MARL_PERSIST_WAVES 4  // waves per SIMD the register allocator must leave room for (<= 128 VGPRs)
+#endif
+template <int BLK, int CPT, int LAYOUT, int NSTEPS>
+__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MARL_PERSIST_WAVES, 8))) rk4_persistent_kernel(const double* __restrict__ yin, double* __restrict__ yout,
+                                                             const DevConsts* __restrict__ consts, Slab S, double dt, int64_t nwin)
+{
+    constexpr int H = 4 * NSTEPS;
+    constexpr int WIN = BLK * CPT;
+    constexpr int V = WIN - 2 * H;
+    static_assert(V > 0, "window too small for the fused halo");
+    __shared__ double lds[StencilBlock<BLK, CPT>::LDS_DOUBLES];
+    const DevConsts& C = consts[0];
+    const int64_t tl = (int64_t)threadIdx.x * CPT - H;  // thread's first cell relative to the window's first OUTPUT cell
+    int64_t win = blockIdx.x;
+    if (win >= nwin) return;
+    int64_t l0 = S.out_lo + win * V + tl;
+    StencilBlock<BLK, CPT> sb(lds, l0 + S.goff, consts);
+    double y[CPT][NF], ys[CPT][NF], k[CPT][NF], acc[CPT][NF], ynext[CPT][NF];
+    PointAux aux[CPT];
+    load_cells<CPT, LAYOUT>(yin, l0, S, C, ynext);
+    const double h2 = 0.5 * dt, h6 = dt / 6.0;
+#define MARL_CELLS _Pragma("unroll") for (int c = 0; c < CPT; c++) _Pragma("unroll") for (int f = 0; f < NF; f++)
+#pragma unroll 1
+    while (true) {
+        MARL_CELLS y[c][f] = ynext[c][f];
+        const int64_t nxt = win + gridDim.x;
+        const int64_t l0n = S.out_lo + nxt * V + tl;
+#ifndef MARL_NO_PREFETCH
+        if (nxt < nwin) load_cells<CPT, LAYOUT>(yin, l0n, S, C, ynext);  // prefetch: consumed one iteration later
+#endif
+#pragma unroll 1
+        for (int step = 0; step < NSTEPS; step++) {
+            sb.eval(y, k, aux);
+            MARL_CELLS { acc[c][f] = k[c][f]; ys[c][f] = y[c][f] + h2 * k[c][f]; }
+            sb.eval(ys, k, aux);
+            MARL_CELLS { acc[c][f] = acc[c][f] + 2.0 * k[c][f]; ys[c][f] = y[c][f] + h2 * k[c][f]; }
+            sb.eval(ys, k, aux);
+            MARL_CELLS { acc[c][f] = acc[c][f] + 2.0 * k[c][f]; ys[c][f] = y[c][f] + dt * k[c][f]; }
+            sb.eval(ys, k, aux);
+            MARL_CELLS y[c][f] = y[c][f] + h6 * (acc[c][f] + k[c][f]);
+        }
+#pragma unroll
+        for (int c = 0; c < CPT; c++) {
+            const int wi = threadIdx.x * CPT + c;
+            const int64_t l = l0 + c;
+            if (wi >= H && wi < WIN - H && l >= S.out_lo && l < S.out_hi) {
+#pragma unroll
+                for (int f = 0; f < NF; f++) yout[at<LAYOUT>(f, l, S.ld)] = y[c][f];
+            }
+        }
+        if (nxt >= nwin) break;
+        win = nxt;
+        l0 = l0n;
+        sb.set_window(l0 + S.goff);
+#ifdef MARL_NO_PREFETCH
+        load_cells<CPT, LAYOUT>(yin, l0, S, C, ynext);
+#endif
+    }
+#undef MARL_CELLS
 }
 
 // ---------------------------------------------------------------------------------------------

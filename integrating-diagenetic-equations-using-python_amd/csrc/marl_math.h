@@ -111,8 +111,9 @@ __device__ __forceinline__ Tables load_tables(double* lds, int nthreads)
 
 __device__ __forceinline__ double fast_log(double x, const Tables& T)
 {
-    // positive normal numbers only; everything else (<= 0, subnormal, inf, NaN) through OCML
-    if (!__builtin_amdgcn_class(x, 1 << 8)) return log(x);
+    // Straight-line main path (the table read can be scheduled early, among independent work); operands that
+    // are not positive normal numbers (<= 0, subnormal, inf, NaN) are redone by OCML afterwards - a branch no
+    // wave takes on a valid state.
     const uint32_t hi = (uint32_t)__double2hiint(x), lo = (uint32_t)__double2loint(x);
     const int32_t t = (int32_t)(hi - 0x3fe60000u);
     const int i = (t >> 13) & (tab::N - 1);
@@ -123,7 +124,9 @@ __device__ __forceinline__ double fast_log(double x, const Tables& T)
     const double r2 = r * r;
     // log1p(r) - r = r^2 (-1/2 + r/3 - r^2/4 + r^3/5 - r^4/6),  |r| < 2^-8: truncation < 2e-18
     const double p = __builtin_fma(r, 1.0 / 3, -0.5) + r2 * (__builtin_fma(r, 1.0 / 5, -0.25) + r2 * (-1.0 / 6));
-    return __builtin_fma((double)k, tab::LN2, logc) + __builtin_fma(r2, p, r);
+    double res = __builtin_fma((double)k, tab::LN2, logc) + __builtin_fma(r2, p, r);
+    if (__builtin_expect(!__builtin_amdgcn_class(x, 1 << 8), 0)) res = log(x);
+    return res;
 }
 
 __device__ __forceinline__ double fast_exp(double x, const Tables& T)
@@ -181,15 +184,32 @@ __device__ __forceinline__ void rhs_point(const double (&uc)[NF], const double (
                                           bool in_mask, const HotConsts& K, const DevConsts* __restrict__ C,
                                           const Tables& T, double (&r)[NF], PointAux& aux)
 {
+#ifdef MARL_ABLATE_CORE  // kernel-lab builds only: the skeleton (loads, LDS exchange, barriers, RK combinations)
+    for (int f = 0; f < NF; f++) r[f] = (up[f] - um[f]) * K.hdx * 1e-9;
+    aux.U = aux.W = 0.0;
+    return;
+#endif
     const double CA = uc[0], CC = uc[1], c = uc[2], o = uc[3], Phi = uc[4];
 
     // ---- porosity-only quantities: F, U, W, den (:414-429).  ONE reciprocal serves 1/Phi, 1/(1-Phi), 1/den.
     const double omPhi = 1.0 - Phi;
+#ifdef MARL_ABLATE_LOG  // kernel-lab builds only (tools/rk4_lab.hip): price of the pieces
+    const double den = __builtin_fma(-2.0, Phi - 1.0, 1.0);
+#else
     const double den = __builtin_fma(-2.0, fast_log(Phi, T), 1.0);
+#endif
     const double pd = Phi * den, od = omPhi * den, po = Phi * omPhi;
+#ifdef MARL_ABLATE_RCP
+    const double rall = 2.0 - pd * omPhi;
+#else
     const double rall = rcp_nr(pd * omPhi);
+#endif
     const double invPhi = rall * od, invom = rall * pd, invden = rall * po;
+#ifdef MARL_ABLATE_EXP
+    const double F = 1.0 - 0.01 * __builtin_fma(-10.0, invPhi, 10.0);
+#else
     const double F = 1.0 - fast_exp(__builtin_fma(-10.0, invPhi, 10.0), T);
+#endif
     const double rF = K.rhorat * F;
     const double t2 = rF * (Phi * Phi);
     const double W = K.presum - t2;
@@ -210,7 +230,11 @@ __device__ __forceinline__ void rhs_point(const double (&uc)[NF], const double (
     const double O3 = O2 * K.KRat;
     const bool under = O3 < 1.0;
     const bool over = O2 > 1.0;
+#ifdef MARL_ABLATE_POW
+    const double pwC = fabs(O2 - 1.0) * (over ? K.n1 : K.n2);
+#else
     const double pwC = pow_sat(fabs(O2 - 1.0), over ? K.n1 : K.n2, T);
+#endif
     double tC = (over ? 1.0 : -K.nu2) * pwC;   // (O2-1)^n1  |  -nu2 (1-O2)^n2
     double tA = O3 - O3;                        // 0, or NaN for a non-finite O3 (keeps the reference's NaN visible)
     if (!under || in_mask) {
