@@ -322,7 +322,7 @@ __device__ __forceinline__ void load_cells(const double* __restrict__ y, int64_t
 // ---------------------------------------------------------------------------------------------
 // Fused classical RK4: NSTEPS whole steps per launch (BASELINE config 2 / headline).
 //   k1 = f(y); k2 = f(y + dt/2 k1); k3 = f(y + dt/2 k2); k4 = f(y + dt k3)
-//   y <- y + dt/6 (((k1 + 2 k2) + 2 k3) + k4)                 (same order as oracle/marl_oracle.c)
+//   y <- y + dt/6 (((k1 + 2 k2) + 2 k3) + k4)                 (the order the CPU checker uses too)
 // ---------------------------------------------------------------------------------------------
 #ifdef MARL_LAB_CLOCK  // kernel-lab diagnostic build only: in-kernel shader clock (s_memtime) vs 100 MHz s_memrealtime
 __device__ unsigned long long marl_lab_clock[3 * 16384];
