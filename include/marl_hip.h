@@ -103,6 +103,31 @@ int marl_integrate_rk45_dev(marl_ctx* ctx, double* y_dev, int layout, double t0,
 int marl_sweep_rk45_dev(marl_ctx* ctx, double* y_dev, double t0, double t1, double first_step, double rtol,
                         double atol, int64_t max_attempts, marl_stats* stats);
 
+/* ---- 1-D domain decomposition of ONE large grid (BASELINE config 5; the reference never decomposes the depth
+ * axis).  One process per GPU holds a slab [g_begin, g_end) of the N_global cells in a slab context; the host
+ * layer moves halo strips between neighbours and the per-rank reduction records to everybody (RCCL
+ * send/recv + all-gather on the context's stream) between these calls - see domain.py.  Slab state lives in the
+ * context (FIELD-MAJOR, `halo` >= 6 extra cells on each interior side).  Strips are 2 x 5 x halo doubles:
+ * [y | f][field][cell].  `which`: 0/1 an explicit state buffer, -1 the buffer the attempt in flight wrote,
+ * -2 the current one.  Sequence:
+ *   load -> pack(0) <-> unpack(0) -> rhs0 -> pack(0) <-> unpack(0) -> monitors -> [all-gather] -> init_control
+ *   per attempt: attempt -> pack(-1) <-> unpack(-1) -> [all-gather records] -> control;   finally store.
+ * Every rank feeds the SAME gathered records (in rank order) to init_control / control, so all ranks take
+ * bit-identical accept/reject decisions without further synchronisation. */
+int marl_ctx_create_slab(const marl_params* params, int64_t N_global, int64_t g_begin, int64_t g_end, int64_t halo,
+                         int device, marl_ctx** out);
+int marl_slab_load(marl_ctx* ctx, const double* y_owned_dev);  /* [5][g_end - g_begin] */
+int marl_slab_store(marl_ctx* ctx, double* y_owned_dev);
+int marl_slab_pack(marl_ctx* ctx, int which, double* send_lo_dev, double* send_hi_dev);
+int marl_slab_unpack(marl_ctx* ctx, int which, const double* recv_lo_dev, const double* recv_hi_dev);
+int marl_slab_rhs0(marl_ctx* ctx);                             /* f(t0, y0) on the owned cells */
+int marl_slab_monitors(marl_ctx* ctx, double* rec_dev);        /* 8-double record of y0's monitors (owned cells) */
+int marl_slab_init_control(marl_ctx* ctx, const double* recs_dev, int64_t nrec, double t0, double t1,
+                           double first_step, double rtol, double atol, int64_t max_attempts);
+int marl_slab_attempt(marl_ctx* ctx, double* rec_dev);         /* one fused Dormand-Prince attempt + its record */
+int marl_slab_control(marl_ctx* ctx, const double* recs_dev, int64_t nrec);
+int marl_slab_status(marl_ctx* ctx, marl_stats* stats);        /* synchronises */
+
 #ifdef __cplusplus
 }
 #endif

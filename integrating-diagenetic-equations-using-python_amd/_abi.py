@@ -64,6 +64,17 @@ PROTOTYPES = {
     "marl_integrate_rk45": (_I, [_P, _P, _D, _D, _D, _D, _D, _P, _L, _P, _P, _L, _L, C.POINTER(MarlStats)]),
     "marl_integrate_rk45_dev": (_I, [_P, _P, _I, _D, _D, _D, _D, _D, _L, C.POINTER(MarlStats)]),
     "marl_sweep_rk45_dev": (_I, [_P, _P, _D, _D, _D, _D, _D, _L, C.POINTER(MarlStats)]),
+    "marl_ctx_create_slab": (_I, [C.POINTER(MarlParams), _L, _L, _L, _L, _I, C.POINTER(_P)]),
+    "marl_slab_load": (_I, [_P, _P]),
+    "marl_slab_store": (_I, [_P, _P]),
+    "marl_slab_pack": (_I, [_P, _I, _P, _P]),
+    "marl_slab_unpack": (_I, [_P, _I, _P, _P]),
+    "marl_slab_rhs0": (_I, [_P]),
+    "marl_slab_monitors": (_I, [_P, _P]),
+    "marl_slab_init_control": (_I, [_P, _P, _L, _D, _D, _D, _D, _D, _L]),
+    "marl_slab_attempt": (_I, [_P, _P]),
+    "marl_slab_control": (_I, [_P, _P, _L]),
+    "marl_slab_status": (_I, [_P, C.POINTER(MarlStats)]),
 }
 
 _lib = None

@@ -23,6 +23,7 @@ struct marl_ctx {
     hipStream_t stream = nullptr;  // nullptr = the device's default (null) stream, which is also torch's default current stream
     int64_t N = 0, batch = 0;
     Slab slab{};
+    int halo = 0;  // > 0: a slab context of a domain-decomposed grid
     std::vector<marl_params> params;
     std::vector<DevConsts> hconsts;
     std::vector<double> extra;  // per instance: delta_x, auxcon, rhorat0, F_fixed (not needed on device)
@@ -845,6 +846,145 @@ int marl_integrate_rk45(marl_ctx* ctx, double* y, double t0, double t1, double f
     }
     if (yev) (void)hipFree(yev);
     return rc;
+}
+
+
+// ---- domain decomposition building blocks --------------------------------------------------------
+int marl_ctx_create_slab(const marl_params* params, int64_t N_global, int64_t g_begin, int64_t g_end, int64_t halo, int device,
+                         marl_ctx** out)
+{
+    if (!params || !out || N_global < 2 || g_begin < 0 || g_end > N_global || g_end <= g_begin)
+        return fail(nullptr, -1, "marl_ctx_create_slab: invalid argument");
+    if (halo < 6) return fail(nullptr, -1, "marl_ctx_create_slab: halo must be >= 6 (one Dormand-Prince attempt consumes 6 cells per side)");
+    if (g_end - g_begin < halo) return fail(nullptr, -1, "marl_ctx_create_slab: slab narrower than the halo");
+    marl_ctx* ctx = nullptr;
+    if (int rc = marl_ctx_create(params, 1, N_global, device, &ctx)) return rc;
+    const int64_t hl = g_begin > 0 ? halo : 0, hr = g_end < N_global ? halo : 0, n_own = g_end - g_begin;
+    ctx->halo = (int)halo;
+    ctx->slab = Slab{hl + n_own + hr, g_begin - hl, hl + n_own + hr, hl, hl + n_own};
+    *out = ctx;
+    return 0;
+}
+
+#define SLAB_OK(ctx, fn)                                                                       \
+    if (!(ctx)) return -1;                                                                     \
+    if ((ctx)->halo <= 0) return fail(ctx, -1, fn ": not a slab context (marl_ctx_create_slab)"); \
+    HIP_OK(ctx, hipSetDevice((ctx)->device));
+
+int marl_slab_load(marl_ctx* ctx, const double* y_owned_dev)
+{
+    SLAB_OK(ctx, "marl_slab_load")
+    if (!y_owned_dev) return fail(ctx, -1, "marl_slab_load: invalid argument");
+    const size_t sd = (size_t)NF * ctx->slab.n_buf;
+    for (int i = 0; i < 4; i++) {
+        if (int rc = ensure(ctx, i, sd)) return rc;
+        HIP_OK(ctx, hipMemsetAsync(ctx->buf[i], 0, sd * sizeof(double), ctx->stream));
+    }
+    const int64_t n_own = ctx->slab.out_hi - ctx->slab.out_lo;
+    hipLaunchKernelGGL(slab_copy_kernel, dim3((unsigned)((n_own + 255) / 256)), dim3(256), 0, ctx->stream, ctx->buf[0], ctx->buf[1], ctx->dctrl, 0,
+                       ctx->slab, const_cast<double*>(y_owned_dev), 0);
+    LAUNCH_OK(ctx);
+    return 0;
+}
+
+int marl_slab_store(marl_ctx* ctx, double* y_owned_dev)
+{
+    SLAB_OK(ctx, "marl_slab_store")
+    if (!y_owned_dev) return fail(ctx, -1, "marl_slab_store: invalid argument");
+    const int64_t n_own = ctx->slab.out_hi - ctx->slab.out_lo;
+    hipLaunchKernelGGL(slab_copy_kernel, dim3((unsigned)((n_own + 255) / 256)), dim3(256), 0, ctx->stream, ctx->buf[0], ctx->buf[1], ctx->dctrl, -2,
+                       ctx->slab, y_owned_dev, 1);
+    LAUNCH_OK(ctx);
+    return 0;
+}
+
+int marl_slab_pack(marl_ctx* ctx, int which, double* send_lo_dev, double* send_hi_dev)
+{
+    SLAB_OK(ctx, "marl_slab_pack")
+    hipLaunchKernelGGL(slab_pack_kernel, dim3(1), dim3(128), 0, ctx->stream, ctx->buf[0], ctx->buf[1], ctx->buf[2], ctx->buf[3], ctx->dctrl, which,
+                       ctx->slab, ctx->halo, send_lo_dev, send_hi_dev);
+    LAUNCH_OK(ctx);
+    return 0;
+}
+
+int marl_slab_unpack(marl_ctx* ctx, int which, const double* recv_lo_dev, const double* recv_hi_dev)
+{
+    SLAB_OK(ctx, "marl_slab_unpack")
+    // a side without a neighbour (physical boundary) has no halo cells: ignore its strip
+    const double* lo = ctx->slab.out_lo > 0 ? recv_lo_dev : nullptr;
+    const double* hi = ctx->slab.out_hi < ctx->slab.n_buf ? recv_hi_dev : nullptr;
+    hipLaunchKernelGGL(slab_unpack_kernel, dim3(1), dim3(128), 0, ctx->stream, ctx->buf[0], ctx->buf[1], ctx->buf[2], ctx->buf[3], ctx->dctrl, which,
+                       ctx->slab, ctx->halo, lo, hi);
+    LAUNCH_OK(ctx);
+    return 0;
+}
+
+int marl_slab_rhs0(marl_ctx* ctx)
+{
+    SLAB_OK(ctx, "marl_slab_rhs0")
+    return launch_rhs(ctx, ctx->buf[0], ctx->buf[2], LAYOUT_FIELD_MAJOR);
+}
+
+int marl_slab_monitors(marl_ctx* ctx, double* rec_dev)
+{
+    SLAB_OK(ctx, "marl_slab_monitors")
+    if (!rec_dev) return fail(ctx, -1, "marl_slab_monitors: invalid argument");
+    if (int rc = launch_monitors(ctx, ctx->buf[0], LAYOUT_FIELD_MAJOR)) return rc;
+    HIP_OK(ctx, hipMemcpyAsync(rec_dev, ctx->rec, sizeof(double) * NQ, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+
+int marl_slab_init_control(marl_ctx* ctx, const double* recs_dev, int64_t nrec, double t0, double t1, double first_step, double rtol,
+                           double atol, int64_t max_attempts)
+{
+    SLAB_OK(ctx, "marl_slab_init_control")
+    if (!recs_dev || nrec < 1) return fail(ctx, -1, "marl_slab_init_control: invalid argument");
+    if (!(first_step > 0) || !(t1 >= t0) || (t1 > t0 && first_step > t1 - t0)) return fail(ctx, -1, "rk45: `first_step` must be in (0, t1 - t0]");
+    hipLaunchKernelGGL(reduce_records_kernel, dim3(1), dim3(256), 0, ctx->stream, recs_dev, nrec, ctx->rec);
+    LAUNCH_OK(ctx);
+    hipLaunchKernelGGL(rk45_init_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->dctrl, ctx->rec, t0, t1, first_step, rtol, atol,
+                       (int64_t)NF * ctx->N, max_attempts, 0);
+    LAUNCH_OK(ctx);
+    return 0;
+}
+
+int marl_slab_attempt(marl_ctx* ctx, double* rec_dev)
+{
+    SLAB_OK(ctx, "marl_slab_attempt")
+    if (!rec_dev) return fail(ctx, -1, "marl_slab_attempt: invalid argument");
+    const int v = default_rk45_variant(ctx);
+    const int64_t nb = rk45_blocks(ctx, v);
+    if (int rc = ensure_part(ctx, (size_t)std::max<int64_t>(nb, 1024))) return rc;
+    switch (v) {
+        case 0: launch_attempt_t<256, 1>(ctx, nb, LAYOUT_FIELD_MAJOR); break;
+        case 1: launch_attempt_t<256, 2>(ctx, nb, LAYOUT_FIELD_MAJOR); break;
+        case 2: launch_attempt_t<512, 1>(ctx, nb, LAYOUT_FIELD_MAJOR); break;
+        default: launch_attempt_t<128, 1>(ctx, nb, LAYOUT_FIELD_MAJOR); break;
+    }
+    LAUNCH_OK(ctx);
+    // one record for this rank; harmless (stale partials) when the controller is no longer running: control ignores it
+    hipLaunchKernelGGL(reduce_records_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->part, nb, rec_dev);
+    LAUNCH_OK(ctx);
+    return 0;
+}
+
+int marl_slab_control(marl_ctx* ctx, const double* recs_dev, int64_t nrec)
+{
+    SLAB_OK(ctx, "marl_slab_control")
+    if (!recs_dev || nrec < 1) return fail(ctx, -1, "marl_slab_control: invalid argument");
+    hipLaunchKernelGGL(rk45_control_kernel, dim3(1), dim3(256), 0, ctx->stream, recs_dev, nrec, ctx->dctrl);
+    LAUNCH_OK(ctx);
+    return 0;
+}
+
+int marl_slab_status(marl_ctx* ctx, marl_stats* stats)
+{
+    SLAB_OK(ctx, "marl_slab_status")
+    if (!stats) return fail(ctx, -1, "marl_slab_status: invalid argument");
+    HIP_OK(ctx, hipMemcpyAsync(ctx->hctrl, ctx->dctrl, sizeof(Rk45Ctrl), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    ctrl_to_stats(*ctx->hctrl, stats);
+    return 0;
 }
 
 }  // extern "C"

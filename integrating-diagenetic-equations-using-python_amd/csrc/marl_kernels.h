@@ -792,6 +792,67 @@ __global__ void __launch_bounds__(BLK) rk45_dense_kernel(const double* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// Domain decomposition (BASELINE config 5): a rank's slab buffer carries `halo` exchanged cells on each
+// interior side.  pack: the slab's first / last `halo` OWNED cells of (y, f) -> contiguous strips
+// [array(2)][field(5)][halo] for the neighbours; unpack: received strips -> the halo cells.
+// `which`: 0 / 1 = explicit buffer; -1 = the buffer the attempt in flight wrote (cur ^ 1); -2 = cur.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int slab_which(int which, const Rk45Ctrl* ctrl)
+{
+    return which >= 0 ? which : (which == -1 ? (ctrl->cur ^ 1) : ctrl->cur);
+}
+
+__global__ void __launch_bounds__(128) slab_pack_kernel(const double* __restrict__ Y0, const double* __restrict__ Y1,
+                                                        const double* __restrict__ F0, const double* __restrict__ F1,
+                                                        const Rk45Ctrl* __restrict__ ctrl, int which, Slab S, int halo,
+                                                        double* __restrict__ send_lo, double* __restrict__ send_hi)
+{
+    const int w = slab_which(which, ctrl);
+    const double* Y = w ? Y1 : Y0;
+    const double* F = w ? F1 : F0;
+    const int n = 2 * NF * halo;
+    for (int i = threadIdx.x; i < n; i += 128) {
+        const int a = i / (NF * halo), f = (i / halo) % NF, j = i % halo;
+        const double* src = a ? F : Y;
+        if (send_lo) send_lo[i] = src[at<LAYOUT_FIELD_MAJOR>(f, S.out_lo + j, S.ld)];
+        if (send_hi) send_hi[i] = src[at<LAYOUT_FIELD_MAJOR>(f, S.out_hi - halo + j, S.ld)];
+    }
+}
+
+__global__ void __launch_bounds__(128) slab_unpack_kernel(double* __restrict__ Y0, double* __restrict__ Y1,
+                                                          double* __restrict__ F0, double* __restrict__ F1,
+                                                          const Rk45Ctrl* __restrict__ ctrl, int which, Slab S, int halo,
+                                                          const double* __restrict__ recv_lo, const double* __restrict__ recv_hi)
+{
+    const int w = slab_which(which, ctrl);
+    double* Y = w ? Y1 : Y0;
+    double* F = w ? F1 : F0;
+    const int n = 2 * NF * halo;
+    for (int i = threadIdx.x; i < n; i += 128) {
+        const int a = i / (NF * halo), f = (i / halo) % NF, j = i % halo;
+        double* dst = a ? F : Y;
+        if (recv_lo) dst[at<LAYOUT_FIELD_MAJOR>(f, S.out_lo - halo + j, S.ld)] = recv_lo[i];
+        if (recv_hi) dst[at<LAYOUT_FIELD_MAJOR>(f, S.out_hi + j, S.ld)] = recv_hi[i];
+    }
+}
+
+// owned cells of a slab <-> a dense [5][n_own] array
+__global__ void __launch_bounds__(256) slab_copy_kernel(double* __restrict__ Y0, double* __restrict__ Y1,
+                                                        const Rk45Ctrl* __restrict__ ctrl, int which, Slab S,
+                                                        double* __restrict__ dense, int to_dense)
+{
+    double* Y = slab_which(which, ctrl) ? Y1 : Y0;
+    const int64_t n_own = S.out_hi - S.out_lo;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_own) return;
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+        if (to_dense) dense[f * n_own + i] = Y[at<LAYOUT_FIELD_MAJOR>(f, S.out_lo + i, S.ld)];
+        else Y[at<LAYOUT_FIELD_MAJOR>(f, S.out_lo + i, S.ld)] = dense[f * n_own + i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Batched parameter sweep (BASELINE configs 3-4): ONE workgroup integrates ONE instance
 // (N <= BLK*CPT cells) for all its steps.  State, stage vectors and the step controller stay
 // on-chip for the whole integration; global memory is touched at entry and exit only.

@@ -1,0 +1,194 @@
+"""One very large depth grid across several GPUs: 1-D domain decomposition with halo exchange.
+
+Not in the reference (it never decomposes the depth axis) - this is BASELINE config 5.
+One process per GPU (``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm).  Rank r owns the
+contiguous cells [N r / P, N (r+1) / P); its slab buffer carries ``halo`` cells of each neighbour.  A fused
+Dormand-Prince attempt consumes 6 cells of halo per side (marl_kernels.h), so ONE exchange per attempt
+suffices: 2 arrays (y_new, f_new) x 5 fields x halo cells = 480 B per side - pure latency, sent with paired
+``isend``/``irecv`` to the two depth neighbours only (a chain: each pair sits on its own xGMI link).  The step
+controller needs the global error norm: each rank reduces its cells to one 8-double record, the records are
+all-gathered and every rank combines them IN RANK ORDER, so all ranks take bit-identical accept/reject
+decisions.  No host synchronisation inside the loop: kernels and collectives are enqueued on one stream, the
+controller state lives on the device, and the host only polls the status every ``poll`` attempts.
+
+The arithmetic is behind a small engine interface so that the driver logic is testable on CPU (gloo) with a
+reference engine injected by the tests; the product engine is :class:`HipSlabEngine` (C ABI, marl_slab_*).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+HALO = 6          # cells per side consumed by one fused attempt
+STRIP = 2 * 5     # (y, f) x five fields
+
+
+def partition(N, world):
+    """Contiguous, near-even split of N cells: list of (begin, end) per rank."""
+    edges = [(N * r) // world for r in range(world + 1)]
+    return [(edges[r], edges[r + 1]) for r in range(world)]
+
+
+class HipSlabEngine:
+    """A rank's slab on its GPU (marl_ctx_create_slab and the marl_slab_* calls)."""
+
+    def __init__(self, pde_parms, N_global, begin, end, device, halo=HALO):
+        import torch
+        from .LHeureux_model import LMAHeureuxPorosityDiff  # noqa: F401  (packing helper below mirrors its ctor)
+        self.torch = torch
+        self.lib = _abi.load()
+        self.ctx = C.c_void_p()
+        blk = _abi.MarlParams()
+        for name in _abi.PARAM_DOUBLES[:30]:
+            setattr(blk, name, float(pde_parms[name]))
+        blk.length = float(pde_parms["max_depth"] / pde_parms["Xstar"])
+        blk.shallow_limit = float(pde_parms["ShallowLimit"]) / float(pde_parms["Xstar"])
+        blk.deep_limit = float(pde_parms["DeepLimit"]) / float(pde_parms["Xstar"])
+        blk.FV_switch = int(pde_parms["FV_switch"])
+        rc = self.lib.marl_ctx_create_slab(C.byref(blk), N_global, begin, end, halo, device, C.byref(self.ctx))
+        if rc != 0:
+            self.ctx = C.c_void_p()
+            _abi.check(None, rc, "marl_ctx_create_slab")
+        self.device = torch.device("cuda", device)
+        self.n_own = end - begin
+        _abi.check(self.ctx, self.lib.marl_set_stream(self.ctx, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                   "marl_set_stream")
+
+    def _call(self, name, *args):
+        _abi.check(self.ctx, getattr(self.lib, name)(self.ctx, *args), name)
+
+    @staticmethod
+    def _p(t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    def new_tensor(self, n):
+        return self.torch.zeros(n, dtype=self.torch.float64, device=self.device)
+
+    def load(self, y_owned):
+        self._call("marl_slab_load", self._p(y_owned))
+
+    def store(self, y_owned):
+        self._call("marl_slab_store", self._p(y_owned))
+
+    def pack(self, which, send_lo, send_hi):
+        self._call("marl_slab_pack", which, self._p(send_lo), self._p(send_hi))
+
+    def unpack(self, which, recv_lo, recv_hi):
+        self._call("marl_slab_unpack", which, self._p(recv_lo), self._p(recv_hi))
+
+    def rhs0(self):
+        self._call("marl_slab_rhs0")
+
+    def monitors(self, rec):
+        self._call("marl_slab_monitors", self._p(rec))
+
+    def init_control(self, recs, nrec, t0, t1, first_step, rtol, atol, max_attempts):
+        self._call("marl_slab_init_control", self._p(recs), nrec, t0, t1, first_step, rtol, atol, max_attempts)
+
+    def attempt(self, rec):
+        self._call("marl_slab_attempt", self._p(rec))
+
+    def control(self, recs, nrec):
+        self._call("marl_slab_control", self._p(recs), nrec)
+
+    def status(self):
+        st = _abi.MarlStats()
+        self._call("marl_slab_status", C.byref(st))
+        return st
+
+    def close(self):
+        if self.ctx:
+            self.lib.marl_ctx_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+
+class DomainDecomposedRK45:
+    """Adaptive RK45 of one N-cell grid over all ranks of ``group``.
+
+    ``engine_factory(begin, end) -> engine`` builds the rank's slab engine (default: HipSlabEngine on
+    ``cuda:LOCAL_RANK``)."""
+
+    def __init__(self, pde_parms, N, group=None, device=None, engine_factory=None, halo=HALO, poll=16):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.N = int(N)
+        self.halo = halo
+        self.poll = poll
+        self.parts = partition(self.N, self.world)
+        self.begin, self.end = self.parts[self.rank]
+        if min(e - b for b, e in self.parts) < halo:
+            raise ValueError(f"N = {N} is too small for {self.world} slabs with a halo of {halo} cells")
+        if engine_factory is None:
+            dev = self.rank if device is None else device
+            engine_factory = lambda b, e: HipSlabEngine(pde_parms, self.N, b, e, dev, halo)  # noqa: E731
+        self.engine = engine_factory(self.begin, self.end)
+        e = self.engine
+        n = STRIP * halo
+        self.send_lo, self.send_hi = e.new_tensor(n), e.new_tensor(n)
+        self.recv_lo, self.recv_hi = e.new_tensor(n), e.new_tensor(n)
+        self.rec = e.new_tensor(8)
+        self.recs = e.new_tensor(8 * self.world)
+
+    # -- communication ---------------------------------------------------------------------------
+    def _exchange(self):
+        """send_lo -> lower neighbour's recv_hi, send_hi -> upper neighbour's recv_lo (paired P2P ops)."""
+        if self.world == 1:
+            return
+        dist = self.dist
+        ops = []
+        if self.rank > 0:
+            ops += [dist.P2POp(dist.isend, self.send_lo, self.rank - 1, self.group),
+                    dist.P2POp(dist.irecv, self.recv_lo, self.rank - 1, self.group)]
+        if self.rank < self.world - 1:
+            ops += [dist.P2POp(dist.isend, self.send_hi, self.rank + 1, self.group),
+                    dist.P2POp(dist.irecv, self.recv_hi, self.rank + 1, self.group)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+    def _gather_records(self):
+        if self.world == 1:
+            self.recs.copy_(self.rec)
+        else:
+            self.dist.all_gather_into_tensor(self.recs, self.rec, group=self.group)
+
+    def _halo_round(self, which):
+        self.engine.pack(which, self.send_lo, self.send_hi)
+        self._exchange()
+        self.engine.unpack(which, self.recv_lo, self.recv_hi)
+
+    # -- the integration ---------------------------------------------------------------------------
+    def integrate(self, y_owned, t_span, first_step, rtol, atol, max_attempts=0):
+        """``y_owned``: this rank's cells, tensor [5 * n_own] (field-major), advanced in place.
+        Returns the marl_stats of the run (identical on every rank)."""
+        e = self.engine
+        e.load(y_owned)
+        self._halo_round(0)          # y halos
+        e.rhs0()
+        self._halo_round(0)          # f halos (FSAL vector)
+        e.monitors(self.rec)
+        self._gather_records()
+        e.init_control(self.recs, self.world, float(t_span[0]), float(t_span[1]), float(first_step), float(rtol),
+                       float(atol), int(max_attempts))
+        while True:
+            for _ in range(self.poll):
+                e.attempt(self.rec)
+                self._halo_round(-1)
+                self._gather_records()
+                e.control(self.recs, self.world)
+            st = e.status()
+            if st.status != 1:
+                break
+        e.store(y_owned)
+        return st
+
+    def close(self):
+        self.engine.close()
+
+
+def owned_slice(y_global, N, begin, end):
+    """The [5 * (end-begin)] field-major piece of a global field-major state (host helper)."""
+    return np.ascontiguousarray(np.asarray(y_global).reshape(5, N)[:, begin:end]).ravel()

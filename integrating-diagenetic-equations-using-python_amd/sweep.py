@@ -1,0 +1,88 @@
+"""Batched parameter sweeps: many independent model instances, sharded over the GPUs of a node.
+
+Not in the reference (one scenario per process); BASELINE configs 3-4.  Instances are independent - own
+parameters, own step-size controller - so ranks take contiguous index ranges and never communicate in the
+data path ("replicas of the kernel").  On each GPU one workgroup integrates one instance
+entirely on-chip (marl_kernels.h, rk45_sweep_kernel).  Results can be gathered to every rank afterwards
+(control plane only).
+"""
+import numpy as np
+
+
+def shard(n_instances, rank, world):
+    """Contiguous near-even split: the (begin, end) instance range of ``rank``."""
+    return (n_instances * rank) // world, (n_instances * (rank + 1)) // world
+
+
+def product_grid(**axes):
+    """Cartesian product of named parameter axes -> list of override dicts (last axis fastest)."""
+    names = list(axes)
+    grids = np.meshgrid(*[np.asarray(axes[k], dtype=float) for k in names], indexing="ij")
+    return [dict(zip(names, (float(g.flat[i]) for g in grids))) for i in range(grids[0].size)]
+
+
+class HipSweepEngine:
+    """The product engine: LMAHeureuxPorosityDiff with a batch of instances on one GPU."""
+
+    def __init__(self, base_parms, instances, device):
+        import torch
+        from .LHeureux_model import LMAHeureuxPorosityDiff
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        self.model = LMAHeureuxPorosityDiff.from_scenario(base_parms, device=device, instances=instances)
+        self.model.use_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def integrate_rk45(self, y0, t_span, first_step, rtol, atol, max_attempts):
+        """y0: (n_local, 5N) host array.  Returns (y_final (n_local, 5N), list of RK45Result)."""
+        yd = self.torch.from_numpy(np.ascontiguousarray(y0)).to(self.device)
+        res = self.model.sweep_rk45_device(yd.data_ptr(), t_span, first_step, rtol, atol, max_attempts)
+        return yd.cpu().numpy(), res
+
+    def integrate_rk4(self, y0, dt, nsteps):
+        yd = self.torch.from_numpy(np.ascontiguousarray(y0)).to(self.device)
+        self.model.sweep_rk4_device(yd.data_ptr(), dt, nsteps)
+        self.torch.cuda.synchronize(self.device)
+        return yd.cpu().numpy()
+
+    def close(self):
+        self.model.close()
+
+
+def initial_states(base_parms, instances):
+    """Uniform initial state per instance (marlpde/Evolve_scenario.py:76-86), shape (n, 5N)."""
+    N = int(base_parms["N"])
+    out = np.empty((len(instances), 5 * N))
+    for i, inst in enumerate(instances):
+        p = base_parms | inst
+        out[i] = np.repeat([p["CAIni"], p["CCIni"], p["cCaIni"], p["cCO3Ini"], p["PhiIni"]], N)
+    return out
+
+
+def run_sweep_rk45(base_parms, instances, t_span, first_step, rtol, atol, max_attempts=0, y0=None, group=None,
+                   device=None, engine_factory=None, gather=True):
+    """Integrate every instance with adaptive RK45; ranks of ``group`` each take a contiguous shard.
+
+    Returns ``(y_final, status, n_accepted, n_rejected, t_reached)`` - for ALL instances when ``gather``,
+    otherwise for the local shard.  ``engine_factory(base_parms, local_instances) -> engine`` is the test hook;
+    the default is :class:`HipSweepEngine` on ``cuda:rank``."""
+    import torch.distributed as dist
+    on = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if on else 0
+    world = dist.get_world_size(group) if on else 1
+    lo, hi = shard(len(instances), rank, world)
+    local = list(instances[lo:hi])
+    if y0 is None:
+        y0 = initial_states(base_parms, instances)
+    if engine_factory is None:
+        dev = rank if device is None else device
+        engine_factory = lambda bp, inst: HipSweepEngine(bp, inst, dev)  # noqa: E731
+    engine = engine_factory(base_parms, local)
+    y, res = engine.integrate_rk45(np.asarray(y0)[lo:hi], t_span, first_step, rtol, atol, max_attempts)
+    engine.close()
+    summary = np.array([[r.status, r.n_accepted, r.n_rejected, r.t_reached] for r in res], dtype=float).reshape(len(local), 4)
+    if gather and world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, (y, summary), group=group)
+        y = np.concatenate([p[0] for p in parts])
+        summary = np.concatenate([p[1] for p in parts])
+    return y, summary[:, 0].astype(int), summary[:, 1].astype(int), summary[:, 2].astype(int), summary[:, 3]
