@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="rk4_single", choices=["rk4_single", "sweep_rk45", "sweep_rk4", "rk45_single"])
+    ap.add_argument("--workload", default="rk4_single", choices=["rk4_single", "sweep_rk45", "sweep_rk4", "rk45_single", "dd_rk45"])
     ap.add_argument("--n", type=int, default=None, help="cells per grid (default 2^20 single, 1024 sweep)")
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU for the sweep workloads")
     ap.add_argument("--layout", type=int, default=1, help="device layout of single-grid runs: 0 field-major, 1 tiled")
@@ -74,7 +74,7 @@ def main():
         torch.cuda.synchronize()
 
     base = asdict(Map_Scenario())
-    single = args.workload in ("rk4_single", "rk45_single")
+    single = args.workload in ("rk4_single", "rk45_single", "dd_rk45")
     N = args.n or ((1 << 20) if single else 1024)
     steps = args.steps if args.steps is not None else (1000 if single else 2000)
     warmup = args.warmup if args.warmup is not None else (10 if single else 20)
@@ -167,8 +167,35 @@ def main():
         eq.close()
         return wall, ev_ms, {"accepted_steps": r.n_accepted, "rejected_steps": r.n_rejected}
 
+    def run_dd(N, steps, warmup):
+        """BASELINE config 5: ONE grid of N cells split over all ranks, RCCL halo exchange + all-gathered control."""
+        from marlpde_amd.domain import DomainDecomposedRK45, owned_slice
+        p = base | {"N": N}
+        dd = DomainDecomposedRK45(p, N, device=local_rank)
+        y0 = synthetic(p, N)
+        dx2 = ((p["max_depth"] / p["Xstar"]) / N) ** 2
+        own = owned_slice(y0, N, dd.begin, dd.end)
+        out = {}
+
+        def go(n):
+            y = torch.from_numpy(own.copy()).cuda()
+            out["st"] = dd.integrate(y, (0.0, 1.0e9), 0.5 * dx2, 1e-3, 1e-3, max_attempts=n)
+        wall, ev_ms = timed(lambda: go(warmup), lambda: go(steps))
+        st = out["st"]
+        dd.close()
+        return wall, ev_ms, {"accepted_steps": int(st.n_accepted), "rejected_steps": int(st.n_rejected)}
+
     extra = {}
-    if args.workload == "rk4_single":
+    if args.workload == "dd_rk45":
+        N = args.n or (1 << 22)
+        steps = args.steps if args.steps is not None else 500
+        warmup = args.warmup if args.warmup is not None else 16
+        wall, ev_ms, info = run_dd(N, steps, warmup)
+        units = float(N) * steps / world       # per-rank share; `value` multiplies by world below
+        workload = f"dd_rk45 ONE grid N={N} over {world} rank(s), halo exchange + all-gathered step control (BASELINE configs[4])"
+        kernel = "rk45_attempt_kernel"
+        extra.update(info)
+    elif args.workload == "rk4_single":
         wall, ev_ms, dt = run_rk4_single(N, steps, warmup, args.layout, args.variant)
         units = float(N) * steps
         workload = f"rk4_fused_single_grid N={N} fp64 (north_star headline; BASELINE configs[1] shape), dt=0.25dx^2"
@@ -206,11 +233,12 @@ def main():
         from oracle import oracle as orc
         orc.build()
         ncores = min(len(os.sched_getaffinity(0)), 16)  # a 1-GPU box shares its host: 16 CPUs per GPU
-        if single:
+        L = base["max_depth"] / base["Xstar"]
+        if args.workload == "rk4_single":
             Nc, sc = N, (2 if N >= (1 << 19) else max(2, int(2e6 // N)))
             P = orc.params_from_dict(base | {"N": Nc})
             yc = synthetic(base | {"N": Nc}, Nc)
-            dtc = 0.25 * ((base["max_depth"] / base["Xstar"]) / Nc) ** 2
+            dtc = 0.25 * (L / Nc) ** 2
             t0 = time.perf_counter(); orc.rk4(P, Nc, yc, dtc, sc); t1c = time.perf_counter() - t0
             os.environ.setdefault("OMP_NUM_THREADS", str(ncores))
             t0 = time.perf_counter(); orc.rk4(P, Nc, yc, dtc, 4 * sc, omp=True); tomp = time.perf_counter() - t0
@@ -218,6 +246,15 @@ def main():
                    "sample": f"oracle RK4 (C port of the reference's serial loop), N={Nc}, {sc} steps, 1 thread",
                    "value_all_cores": Nc * 4 * sc / tomp, "cores_all": ncores,
                    "sample_all_cores": f"same, OpenMP over cells, {4 * sc} steps, {ncores} threads"}
+        elif single:
+            Nc = min(N, 1 << 20)
+            sc = max(3, int(4e6 // Nc))
+            P = orc.params_from_dict(base | {"N": Nc})
+            t0 = time.perf_counter()
+            orc.rk45(P, Nc, synthetic(base | {"N": Nc}, Nc), 0.0, 1e9, 0.5 * (L / Nc) ** 2, 1e-3, 1e-3, max_attempts=sc, max_steps_out=1)
+            t1c = time.perf_counter() - t0
+            cpu = {"value": Nc * sc / t1c, "unit": "grid-point-steps/s", "cores": 1, "kind": "port",
+                   "sample": f"oracle RK45 (C port, scipy-exact controller), N={Nc}, {sc} attempted steps, 1 thread"}
         else:
             Bc, sc = 16, 200
             inst = [{"Phi0": 0.5 + 0.3 * i / 15, "PhiIni": 0.5 + 0.3 * ((i * 7) % 16) / 15} for i in range(Bc)]
@@ -225,24 +262,35 @@ def main():
             for d in inst:
                 d["PhiNR"] = d["PhiIni"]
                 P = orc.params_from_dict(base | d | {"N": N})
-                orc.rk45(P, N, synthetic(base | d | {"N": N}, N), 0.0, 1e9,
-                         0.5 * ((base["max_depth"] / base["Xstar"]) / N) ** 2, 1e-3, 1e-3, max_attempts=sc)
+                orc.rk45(P, N, synthetic(base | d | {"N": N}, N), 0.0, 1e9, 0.5 * (L / N) ** 2, 1e-3, 1e-3, max_attempts=sc,
+                         max_steps_out=1)
             t1c = time.perf_counter() - t0
             cpu = {"value": N * Bc * sc / t1c, "unit": "grid-point-steps/s", "cores": 1, "kind": "port",
                    "sample": f"oracle RK45 (C port, scipy-exact controller), {Bc} instances x N={N} x {sc} attempts, 1 thread"}
 
     if rank == 0:
-        launches = None
-        achieved = BYTES_PER_POINT_STEP * units / (ev_ms * 1e-3) / 1e9  # GB/s, HIP-event time of the timed region
+        # dominant kernel: algorithmic bytes per launch / average launch duration (HIP events around the timed
+        # region on the launch stream; launches are back to back, so gaps count against the kernel)
+        per_launch = {"rk4_single": 4 if (N > 131072 and args.variant < 0) else None}.get(args.workload)
+        achieved = BYTES_PER_POINT_STEP * units / (ev_ms * 1e-3) / 1e9  # GB/s
+        traffic, traffic_note = None, "no PMC summary committed for this kernel variant"
+        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+        if per_launch and args.workload == "rk4_single" and N == (1 << 20) and os.path.exists(pmc_file):
+            k = json.load(open(pmc_file))["kernels"].get("void marl::rk4_fused_kernel<256, 1, 1, 4>")
+            if k:
+                traffic = k["hbm_bytes_per_launch"]
+                traffic_note = ("HBM bytes per launch (4 RK4 steps) from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                                "FETCH_SIZE doubled per the gfx950 calibration (profiles/r01_pmc_hbm_traffic.json); "
+                                f"algorithmic bytes per launch = {k['algorithmic_bytes_per_launch']}")
         line = {
             "metric": "grid-point-steps/sec (5 fields, fp64)", "value": value, "unit": "grid-point-steps/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * wall_max / steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if args.workload == "dd_rk45" else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "N": N, "instances_per_gpu": (1 if single else args.batch),
                        "layout": ("tiled" if args.layout else "field-major") if single else "field-major",
                        "parallelism": f"{world} independent rank(s), no collectives in the data path"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note, "kernel": kernel,
                          "algorithmic_bytes_per_grid_point_step": BYTES_PER_POINT_STEP,
                          "note": "achieved = 80 B x grid-point-steps / HIP-event time; the kernel is fp64-VALU-bound, see DESIGN.md"},
             "cpu_baseline": cpu,
