@@ -64,6 +64,8 @@ struct StencilBlock {
     int tid;
     int parity;
     unsigned first_mask, last_mask, zone_mask;  // bit c: the thread's c-th cell is global cell 0 / N-1 / in the dissolution zone
+    PointCache cache[CPT];       // transcendental values of the step's first evaluation (marl_math.h, TR_FILL / TR_REUSE)
+    bool reuse_live = false;     // wave-uniform: the cache is filled and no stage of this step has fallen back yet
 
     // lds: LDS_DOUBLES doubles = edge exchange buffers followed by the log/exp tables (copied here; barrier inside).
     // g0: global index of this thread's first cell.
@@ -88,6 +90,8 @@ struct StencilBlock {
     }
 
     // k[c] = RHS(stage state ys) for the thread's CPT cells.  Contains exactly one __syncthreads().
+    // MODE: TR_FILL for the first evaluation of a step / attempt, TR_REUSE for the following ones, TR_PLAIN otherwise.
+    template <int MODE = TR_PLAIN>
     __device__ __forceinline__ void eval(const double (&ys)[CPT][NF], double (&k)[CPT][NF], PointAux (&aux)[CPT])
     {
         double* e = lds + parity * (NSIDE * NF * BLK);
@@ -125,7 +129,7 @@ struct StencilBlock {
                     for (int f = 0; f < NF; f++) um[f] = ghost_lower(C->bc[f], ys[c][f]);
                 }
             }
-            rhs_point(ys[c], um, up, (zone_mask >> c) & 1u, K, C, T, k[c], aux[c]);
+            rhs_point<MODE>(ys[c], um, up, (zone_mask >> c) & 1u, K, C, T, k[c], aux[c], cache[c], reuse_live);
         }
     }
 };
@@ -192,7 +196,9 @@ __global__ void __launch_bounds__(256) rhs_kernel(const double* __restrict__ y, 
 #pragma unroll
     for (int f = 0; f < NF; f++) up[f] = (g < C.N - 1) ? y[at<LAYOUT>(f, l + 1, S.ld)] : ghost_upper(f, uc[f], um[f]);
     const HotConsts K = load_hot(&C);
-    rhs_point(uc, um, up, g >= C.mask_lo && g < C.mask_hi, K, &C, T, r, aux);
+    PointCache pc;
+    bool live = false;
+    rhs_point<TR_PLAIN>(uc, um, up, g >= C.mask_lo && g < C.mask_hi, K, &C, T, r, aux, pc, live);
 #pragma unroll
     for (int f = 0; f < NF; f++) dydt[at<LAYOUT>(f, l, S.ld)] = r[f];
 }
@@ -351,22 +357,22 @@ __global__ void __launch_bounds__(BLK) rk4_fused_kernel(const double* __restrict
 
 #pragma unroll 1
     for (int step = 0; step < NSTEPS; step++) {
-        sb.eval(y, k, aux);
+        sb.template eval<TR_FILL>(y, k, aux);
 #pragma unroll
         for (int c = 0; c < CPT; c++)
 #pragma unroll
             for (int f = 0; f < NF; f++) { acc[c][f] = k[c][f]; ys[c][f] = y[c][f] + h2 * k[c][f]; }
-        sb.eval(ys, k, aux);
+        sb.template eval<TR_REUSE>(ys, k, aux);
 #pragma unroll
         for (int c = 0; c < CPT; c++)
 #pragma unroll
             for (int f = 0; f < NF; f++) { acc[c][f] = acc[c][f] + 2.0 * k[c][f]; ys[c][f] = y[c][f] + h2 * k[c][f]; }
-        sb.eval(ys, k, aux);
+        sb.template eval<TR_REUSE>(ys, k, aux);
 #pragma unroll
         for (int c = 0; c < CPT; c++)
 #pragma unroll
             for (int f = 0; f < NF; f++) { acc[c][f] = acc[c][f] + 2.0 * k[c][f]; ys[c][f] = y[c][f] + dt * k[c][f]; }
-        sb.eval(ys, k, aux);
+        sb.template eval<TR_REUSE>(ys, k, aux);
 #pragma unroll
         for (int c = 0; c < CPT; c++)
 #pragma unroll
@@ -429,13 +435,13 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MARL_P
 #endif
 #pragma unroll 1
         for (int step = 0; step < NSTEPS; step++) {
-            sb.eval(y, k, aux);
+            sb.template eval<TR_FILL>(y, k, aux);
             MARL_CELLS { acc[c][f] = k[c][f]; ys[c][f] = y[c][f] + h2 * k[c][f]; }
-            sb.eval(ys, k, aux);
+            sb.template eval<TR_REUSE>(ys, k, aux);
             MARL_CELLS { acc[c][f] = acc[c][f] + 2.0 * k[c][f]; ys[c][f] = y[c][f] + h2 * k[c][f]; }
-            sb.eval(ys, k, aux);
+            sb.template eval<TR_REUSE>(ys, k, aux);
             MARL_CELLS { acc[c][f] = acc[c][f] + 2.0 * k[c][f]; ys[c][f] = y[c][f] + dt * k[c][f]; }
-            sb.eval(ys, k, aux);
+            sb.template eval<TR_REUSE>(ys, k, aux);
             MARL_CELLS y[c][f] = y[c][f] + h6 * (acc[c][f] + k[c][f]);
         }
 #pragma unroll
@@ -640,20 +646,20 @@ __device__ __forceinline__ void dp45_attempt(StencilBlock<BLK, CPT>& sb, double 
     double ys[CPT][NF], k2[CPT][NF], k3[CPT][NF], k4[CPT][NF], k5[CPT][NF], k6[CPT][NF];
 #define MARL_CELLS _Pragma("unroll") for (int c = 0; c < CPT; c++) _Pragma("unroll") for (int f = 0; f < NF; f++)
     MARL_CELLS ys[c][f] = y[c][f] + (k1[c][f] * dp::A21) * h;
-    sb.eval(ys, k2, aux);
+    sb.template eval<TR_FILL>(ys, k2, aux);
     MARL_CELLS ys[c][f] = y[c][f] + (k1[c][f] * dp::A31 + k2[c][f] * dp::A32) * h;
-    sb.eval(ys, k3, aux);
+    sb.template eval<TR_REUSE>(ys, k3, aux);
     MARL_CELLS ys[c][f] = y[c][f] + (k1[c][f] * dp::A41 + k2[c][f] * dp::A42 + k3[c][f] * dp::A43) * h;
-    sb.eval(ys, k4, aux);
+    sb.template eval<TR_REUSE>(ys, k4, aux);
     MARL_CELLS ys[c][f] = y[c][f] + (k1[c][f] * dp::A51 + k2[c][f] * dp::A52 + k3[c][f] * dp::A53 + k4[c][f] * dp::A54) * h;
-    sb.eval(ys, k5, aux);
+    sb.template eval<TR_REUSE>(ys, k5, aux);
     MARL_CELLS ys[c][f] = y[c][f] + (k1[c][f] * dp::A61 + k2[c][f] * dp::A62 + k3[c][f] * dp::A63 + k4[c][f] * dp::A64 + k5[c][f] * dp::A65) * h;
-    sb.eval(ys, k6, aux);
+    sb.template eval<TR_REUSE>(ys, k6, aux);
     MARL_CELLS {
         yn[c][f] = y[c][f] + h * (k1[c][f] * dp::B1 + k3[c][f] * dp::B3 + k4[c][f] * dp::B4 + k5[c][f] * dp::B5 + k6[c][f] * dp::B6);
         esum[c][f] = k1[c][f] * e1 + k3[c][f] * e3 + k4[c][f] * e4 + k5[c][f] * e5 + k6[c][f] * e6;
     }
-    sb.eval(yn, k7, aux);
+    sb.template eval<TR_REUSE>(yn, k7, aux);
     MARL_CELLS esum[c][f] = esum[c][f] + k7[c][f] * e7;
 #undef MARL_CELLS
 }
@@ -950,13 +956,13 @@ __global__ void __launch_bounds__(BLK) rk4_sweep_kernel(double* __restrict__ Y, 
 #define MARL_CELLS _Pragma("unroll") for (int c = 0; c < CPT; c++) _Pragma("unroll") for (int f = 0; f < NF; f++)
 #pragma unroll 1
     for (int64_t s = 0; s < nsteps; s++) {
-        sb.eval(y, k, aux);
+        sb.template eval<TR_FILL>(y, k, aux);
         MARL_CELLS { acc[c][f] = k[c][f]; ys[c][f] = y[c][f] + h2 * k[c][f]; }
-        sb.eval(ys, k, aux);
+        sb.template eval<TR_REUSE>(ys, k, aux);
         MARL_CELLS { acc[c][f] = acc[c][f] + 2.0 * k[c][f]; ys[c][f] = y[c][f] + h2 * k[c][f]; }
-        sb.eval(ys, k, aux);
+        sb.template eval<TR_REUSE>(ys, k, aux);
         MARL_CELLS { acc[c][f] = acc[c][f] + 2.0 * k[c][f]; ys[c][f] = y[c][f] + dt * k[c][f]; }
-        sb.eval(ys, k, aux);
+        sb.template eval<TR_REUSE>(ys, k, aux);
         MARL_CELLS y[c][f] = y[c][f] + h6 * (acc[c][f] + k[c][f]);
     }
 #undef MARL_CELLS

@@ -177,12 +177,32 @@ struct PointAux {
     double U, W;  // by-products needed by the monitors zeros_U / zeros_W (LHeureux_model.py:567-593)
 };
 
+// Transcendental reuse across the stages of one RK step.  The stage states of an explicit step on a fine grid
+// differ from the step's first state by dt*rate - relatively 1e-10 at N = 2^20, 1e-6 at N = 65 536 - so
+// log(Phi), the reciprocals, exp(10 - 10/Phi) and the saturation power of a LATER stage are given to full fp64
+// accuracy by 3rd-order expansions around the values the FIRST evaluation computed (truncation < 1e-17 while
+// every expansion variable is below REUSE_LIMIT).  The first evaluation fills the cache (TR_FILL); later ones
+// (TR_REUSE) check the variables and fall back to the full evaluation - wave-uniformly - when any lane is out
+// of range (coarse grids, large steps, non-finite states); after one fall-back the remaining stages of that step
+// skip the check.  TR_PLAIN: no cache (stand-alone RHS).
+enum : int { TR_PLAIN = 0, TR_FILL = 1, TR_REUSE = 2 };
+constexpr double REUSE_LIMIT = 5e-5;
+
+struct PointCache {
+    double Phi, invPhi, invom, L, invden, e;  // Phi, 1/Phi, 1/(1-Phi), log Phi, 1/den, exp(10 - 10/Phi)
+    double O2, ib, n, tC;                     // c*o, 1/(c*o - 1), the exponent in use, coefficient * |c*o - 1|^n
+    bool fv_quiet;                            // all three Peclet numbers were < 0.9 PECLET_MIN at the first evaluation
+};
+
 // uc/um/up: values at cell i, i-1, i+1 (ghosts already substituted).  in_mask: cell inside the
 // dissolution zone.  K: hot constants (registers); C: the instance's full constant block (cold parts are
 // read from memory only on rare paths).  r: the five rates (LHeureux_model.py:498-520).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wsometimes-uninitialized"  // den ... tC are set on exactly one of the two paths below
+template <int MODE>
 __device__ __forceinline__ void rhs_point(const double (&uc)[NF], const double (&um)[NF], const double (&up)[NF],
                                           bool in_mask, const HotConsts& K, const DevConsts* __restrict__ C,
-                                          const Tables& T, double (&r)[NF], PointAux& aux)
+                                          const Tables& T, double (&r)[NF], PointAux& aux, PointCache& pc, bool& live)
 {
 #ifdef MARL_ABLATE_CORE  // kernel-lab builds only: the skeleton (loads, LDS exchange, barriers, RK combinations)
     for (int f = 0; f < NF; f++) r[f] = (up[f] - um[f]) * K.hdx * 1e-9;
@@ -190,26 +210,77 @@ __device__ __forceinline__ void rhs_point(const double (&uc)[NF], const double (
     return;
 #endif
     const double CA = uc[0], CC = uc[1], c = uc[2], o = uc[3], Phi = uc[4];
-
-    // ---- porosity-only quantities: F, U, W, den (:414-429).  ONE reciprocal serves 1/Phi, 1/(1-Phi), 1/den.
     const double omPhi = 1.0 - Phi;
+    const double O2 = c * o;
+    const double O3 = O2 * K.KRat;
+    const bool under = O3 < 1.0;
+
+    // ---- porosity-only quantities (:414-429) and the calcite saturation term (:490-491):
+    //      tC = (O2-1)^n1 if O2 > 1 else -nu2 (1-O2)^n2   (one power per clamp pair, see below)
+    double den, invPhi, invom, invden, ex, tC;
+    bool fv_check = K.fv != 0;
+    bool reuse = false;
+    if constexpr (MODE == TR_FILL) live = true;
+    if (MODE == TR_REUSE && live) {   // `live` (wave-uniform): no earlier stage of this step fell back
+        const double d = Phi - pc.Phi;
+        const double x = d * pc.invPhi, y = d * pc.invom, u = (O2 - pc.O2) * pc.ib;
+        const double l1p = x * __builtin_fma(x, __builtin_fma(x, 1.0 / 3, -0.5), 1.0);   // log1p(x)
+        const double z = -2.0 * l1p * pc.invden;                                          // (den - den0)/den0
+        const double ip = pc.invPhi * __builtin_fma(-x, __builtin_fma(-x, 1.0 - x, 1.0), 1.0);  // 1/(Phi0 (1+x))
+        const double da = -10.0 * (ip - pc.invPhi);                                       // change of 10 - 10/Phi
+        const double w = pc.n * (u * __builtin_fma(u, __builtin_fma(u, 1.0 / 3, -0.5), 1.0));   // n log1p(u)
+        const double big = fmax(fmax(fmax(fabs(x), fabs(y)), fmax(fabs(z), fabs(da))), fabs(w));
+        reuse = __builtin_amdgcn_ballot_w64(!(big < REUSE_LIMIT)) == 0;   // NaN compares false -> falls back
+        live = reuse;   // out of range once (coarse grid / large step): stop trying for the rest of this step
+        if (reuse) {
+            invPhi = ip;
+            den = __builtin_fma(-2.0, pc.L + l1p, 1.0);
+            invom = pc.invom * __builtin_fma(y, __builtin_fma(y, 1.0 + y, 1.0), 1.0);     // 1/(1-y)
+            invden = pc.invden * __builtin_fma(-z, __builtin_fma(-z, 1.0 - z, 1.0), 1.0);
+            ex = pc.e * __builtin_fma(da, __builtin_fma(da, __builtin_fma(da, 1.0 / 6, 0.5), 1.0), 1.0);
+            tC = pc.tC * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.0 / 6, 0.5), 1.0), 1.0);
+            fv_check = fv_check && !pc.fv_quiet;
+        }
+    }
+    if (!reuse) {
+        // ONE reciprocal serves 1/Phi, 1/(1-Phi), 1/den.
 #ifdef MARL_ABLATE_LOG  // kernel-lab builds only (tools/rk4_lab.hip): price of the pieces
-    const double den = __builtin_fma(-2.0, Phi - 1.0, 1.0);
+        const double L = Phi - 1.0;
 #else
-    const double den = __builtin_fma(-2.0, fast_log(Phi, T), 1.0);
+        const double L = fast_log(Phi, T);
 #endif
-    const double pd = Phi * den, od = omPhi * den, po = Phi * omPhi;
+        den = __builtin_fma(-2.0, L, 1.0);
+        const double pd = Phi * den, od = omPhi * den, po = Phi * omPhi;
 #ifdef MARL_ABLATE_RCP
-    const double rall = 2.0 - pd * omPhi;
+        const double rall = 2.0 - pd * omPhi;
 #else
-    const double rall = rcp_nr(pd * omPhi);
+        const double rall = rcp_nr(pd * omPhi);
 #endif
-    const double invPhi = rall * od, invom = rall * pd, invden = rall * po;
+        invPhi = rall * od, invom = rall * pd, invden = rall * po;
 #ifdef MARL_ABLATE_EXP
-    const double F = 1.0 - 0.01 * __builtin_fma(-10.0, invPhi, 10.0);
+        ex = 0.01 * __builtin_fma(-10.0, invPhi, 10.0);
 #else
-    const double F = 1.0 - fast_exp(__builtin_fma(-10.0, invPhi, 10.0), T);
+        ex = fast_exp(__builtin_fma(-10.0, invPhi, 10.0), T);
 #endif
+        const bool over = O2 > 1.0;
+        const double nsel = over ? K.n1 : K.n2;
+#ifdef MARL_ABLATE_POW
+        const double pwC = fabs(O2 - 1.0) * nsel;
+#else
+        const double pwC = pow_sat(fabs(O2 - 1.0), nsel, T);
+#endif
+        tC = (over ? 1.0 : -K.nu2) * pwC;
+        if (K.generic_p0) {  // an exponent <= 0: pow(0, e) is 1 or inf instead of 0 (rare; constants from memory)
+            const double y1 = C->p0_n1, y2 = C->p0_n2;
+            const double pcw = (O2 == 1.0) ? (over ? y1 : y2) : pwC;
+            tC = over ? pcw - K.nu2 * y2 : y1 - K.nu2 * pcw;
+        }
+        if constexpr (MODE == TR_FILL) {
+            pc.Phi = Phi; pc.invPhi = invPhi; pc.invom = invom; pc.L = L; pc.invden = invden; pc.e = ex;
+            pc.O2 = O2; pc.ib = K.generic_p0 ? __builtin_nan("") : rcp_nr(O2 - 1.0); pc.n = nsel; pc.tC = tC;
+        }
+    }
+    const double F = 1.0 - ex;
     const double rF = K.rhorat * F;
     const double t2 = rF * (Phi * Phi);
     const double W = K.presum - t2;
@@ -226,28 +297,16 @@ __device__ __forceinline__ void rhs_point(const double (&uc)[NF], const double (
 
     // ---- reaction terms (:479-493).  Of each clamp pair (min(x,1), max(x,1)) one power has base exactly 0
     // and the other has base |x - 1|; with positive exponents the zero-base member vanishes.
-    const double O2 = c * o;
-    const double O3 = O2 * K.KRat;
-    const bool under = O3 < 1.0;
-    const bool over = O2 > 1.0;
-#ifdef MARL_ABLATE_POW
-    const double pwC = fabs(O2 - 1.0) * (over ? K.n1 : K.n2);
-#else
-    const double pwC = pow_sat(fabs(O2 - 1.0), over ? K.n1 : K.n2, T);
-#endif
-    double tC = (over ? 1.0 : -K.nu2) * pwC;   // (O2-1)^n1  |  -nu2 (1-O2)^n2
     double tA = O3 - O3;                        // 0, or NaN for a non-finite O3 (keeps the reference's NaN visible)
     if (!under || in_mask) {
         const double pwA = pow_sat(fabs(O3 - 1.0), under ? K.m2 : K.m1, T);
         tA = (under ? 1.0 : -K.nu1) * pwA;      // (1-O3)^m2 * mask  |  -nu1 (O3-1)^m1
     }
-    if (K.generic_p0) {  // an exponent <= 0: pow(0, e) is 1 or inf instead of 0 (rare; constants from memory)
-        const double z1 = C->p0_m1, z2 = C->p0_m2, y1 = C->p0_n1, y2 = C->p0_n2;
+    if (K.generic_p0) {
+        const double z1 = C->p0_m1, z2 = C->p0_m2;
         const double mask = in_mask ? 1.0 : 0.0;
         const double pa = (O3 == 1.0) ? (under ? z2 : z1) : ((!under || in_mask) ? fast_exp((under ? K.m2 : K.m1) * fast_log(fabs(O3 - 1.0), T), T) : 0.0);
-        const double pc = (O2 == 1.0) ? (over ? y1 : y2) : pwC;
         tA = under ? pa * mask - K.nu1 * z1 : z2 * mask - K.nu1 * pa;
-        tC = over ? pc - K.nu2 * y2 : y1 - K.nu2 * pc;
     }
     const double DA = K.Da * (CA * tA);          // Da coA
     const double DC = K.Dal * (CC * tC);         // Da lambda coC
@@ -262,7 +321,14 @@ __device__ __forceinline__ void rhs_point(const double (&uc)[NF], const double (
     // ---- solutes and porosity.  Fiadeiro-Veronis weights (:433-462) all vanish when every |Pe| < PECLET_MIN
     // (always on fine grids): then the weighted gradient 0.5*((1-s) forw + (1+s) back) is the central one.
     const double Wd = W * den;
-    const bool fv_active = K.fv && !(fabs(Wd) * K.pe_smax < PECLET_MIN && fabs(W) * K.pe_Phi < PECLET_MIN);
+    bool fv_active = false;
+    if (fv_check) {
+        const double pmax = fmax(fabs(Wd) * K.pe_smax, fabs(W) * K.pe_Phi);
+        fv_active = !(pmax < PECLET_MIN);
+        if constexpr (MODE == TR_FILL) pc.fv_quiet = pmax < 0.9 * PECLET_MIN;  // later stages move Pe by < 1e-3 relative
+    } else if constexpr (MODE == TR_FILL) {
+        pc.fv_quiet = true;  // FV_switch off
+    }
     const double h1x = (Phi * invden) * K.inv_dx2;                  // Phi/den / dx^2
     const double h2f = (2.0 + den) * (invden * invden);             // (2+den)/den^2
     const double q = __builtin_fma(rF, __builtin_fma(2.0, Phi, 10.0), -K.rr10);  // rhorat (2 Phi F + 10 (F-1))  (:495)
@@ -286,5 +352,6 @@ __device__ __forceinline__ void rhs_point(const double (&uc)[NF], const double (
     // -(dWdx Phi + W Phi') with dWdx = -q Phi'  ->  -Phi' (W - Phi q)             // :495, :518-520
     r[4] = __builtin_fma(-pg, __builtin_fma(-Phi, q, W), __builtin_fma(K.dPhi * K.inv_dx2, p_d, DaR));
 }
+#pragma clang diagnostic pop
 
 }  // namespace marl
