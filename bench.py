@@ -76,8 +76,8 @@ def main():
     base = asdict(Map_Scenario())
     single = args.workload in ("rk4_single", "rk45_single", "dd_rk45")
     N = args.n or ((1 << 20) if single else 1024)
-    steps = args.steps if args.steps is not None else (1000 if single else 2000)
-    warmup = args.warmup if args.warmup is not None else (10 if single else 20)
+    steps = args.steps if args.steps is not None else (4000 if single else 2000)
+    warmup = args.warmup if args.warmup is not None else (200 if single else 20)   # ~6 ms: lets the clocks settle
 
     def timed(fn_warm, fn_timed):
         """warm-up, then the timed region bracketed by barrier + synchronize; returns (wall s, event ms)."""

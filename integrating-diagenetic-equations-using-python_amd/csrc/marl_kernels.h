@@ -333,8 +333,10 @@ __device__ __forceinline__ void load_cells(const double* __restrict__ y, int64_t
 #ifdef MARL_LAB_CLOCK  // kernel-lab diagnostic build only: in-kernel shader clock (s_memtime) vs 100 MHz s_memrealtime
 __device__ unsigned long long marl_lab_clock[3 * 16384];
 #endif
+// One cell per thread needs ~133 VGPRs; asking for 4 waves per SIMD (<= 128) costs 6 spilled registers and buys
+// +4 % (profiles/r01_lab_*.log).  Variants with more cells per thread keep the compiler's own choice.
 template <int BLK, int CPT, int LAYOUT, int NSTEPS>
-__global__ void __launch_bounds__(BLK) rk4_fused_kernel(const double* __restrict__ yin, double* __restrict__ yout,
+__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(CPT == 1 ? 4 : 1, 8))) rk4_fused_kernel(const double* __restrict__ yin, double* __restrict__ yout,
                                                         const DevConsts* __restrict__ consts, Slab S, double dt)
 {
 #ifdef MARL_LAB_CLOCK

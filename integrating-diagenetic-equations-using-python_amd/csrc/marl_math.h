@@ -186,7 +186,8 @@ struct PointAux {
 // of range (coarse grids, large steps, non-finite states); after one fall-back the remaining stages of that step
 // skip the check.  TR_PLAIN: no cache (stand-alone RHS).
 enum : int { TR_PLAIN = 0, TR_FILL = 1, TR_REUSE = 2 };
-constexpr double REUSE_LIMIT = 5e-5;
+constexpr double REUSE_LIMIT = 5e-5;   // 3rd-order expansions: truncation x^4 < 1e-17
+constexpr double REUSE_TINY = 2e-6;    // below this the 3rd-order terms themselves are < 1e-17: 2nd order suffices
 
 struct PointCache {
     double Phi, invPhi, invom, L, invden, e;  // Phi, 1/Phi, 1/(1-Phi), log Phi, 1/den, exp(10 - 10/Phi)
@@ -224,21 +225,38 @@ __device__ __forceinline__ void rhs_point(const double (&uc)[NF], const double (
     if (MODE == TR_REUSE && live) {   // `live` (wave-uniform): no earlier stage of this step fell back
         const double d = Phi - pc.Phi;
         const double x = d * pc.invPhi, y = d * pc.invom, u = (O2 - pc.O2) * pc.ib;
-        const double l1p = x * __builtin_fma(x, __builtin_fma(x, 1.0 / 3, -0.5), 1.0);   // log1p(x)
-        const double z = -2.0 * l1p * pc.invden;                                          // (den - den0)/den0
-        const double ip = pc.invPhi * __builtin_fma(-x, __builtin_fma(-x, 1.0 - x, 1.0), 1.0);  // 1/(Phi0 (1+x))
-        const double da = -10.0 * (ip - pc.invPhi);                                       // change of 10 - 10/Phi
-        const double w = pc.n * (u * __builtin_fma(u, __builtin_fma(u, 1.0 / 3, -0.5), 1.0));   // n log1p(u)
-        const double big = fmax(fmax(fmax(fabs(x), fabs(y)), fmax(fabs(z), fabs(da))), fabs(w));
+        // first-order estimates of the other expansion variables decide the tier (exact values follow)
+        const double big = fmax(fmax(fmax(fabs(x), fabs(y)), fmax(fabs(u * pc.n), 12.0 * fabs(x * pc.invPhi))), 2.2 * fabs(x * pc.invden));
         reuse = __builtin_amdgcn_ballot_w64(!(big < REUSE_LIMIT)) == 0;   // NaN compares false -> falls back
         live = reuse;   // out of range once (coarse grid / large step): stop trying for the rest of this step
         if (reuse) {
+            const bool tiny = __builtin_amdgcn_ballot_w64(!(big < REUSE_TINY)) == 0;
+            double l1p, ip, w, gy;
+            if (tiny) {
+                l1p = x * __builtin_fma(x, -0.5, 1.0);                                    // log1p(x)
+                ip = pc.invPhi * __builtin_fma(-x, 1.0 - x, 1.0);                         // 1/(Phi0 (1+x))
+                w = pc.n * (u * __builtin_fma(u, -0.5, 1.0));                             // n log1p(u)
+                gy = __builtin_fma(y, 1.0 + y, 1.0);                                      // 1/(1-y)
+            } else {
+                l1p = x * __builtin_fma(x, __builtin_fma(x, 1.0 / 3, -0.5), 1.0);
+                ip = pc.invPhi * __builtin_fma(-x, __builtin_fma(-x, 1.0 - x, 1.0), 1.0);
+                w = pc.n * (u * __builtin_fma(u, __builtin_fma(u, 1.0 / 3, -0.5), 1.0));
+                gy = __builtin_fma(y, __builtin_fma(y, 1.0 + y, 1.0), 1.0);
+            }
+            const double z = -2.0 * l1p * pc.invden;                                      // (den - den0)/den0
+            const double da = -10.0 * (ip - pc.invPhi);                                   // change of 10 - 10/Phi
             invPhi = ip;
             den = __builtin_fma(-2.0, pc.L + l1p, 1.0);
-            invom = pc.invom * __builtin_fma(y, __builtin_fma(y, 1.0 + y, 1.0), 1.0);     // 1/(1-y)
-            invden = pc.invden * __builtin_fma(-z, __builtin_fma(-z, 1.0 - z, 1.0), 1.0);
-            ex = pc.e * __builtin_fma(da, __builtin_fma(da, __builtin_fma(da, 1.0 / 6, 0.5), 1.0), 1.0);
-            tC = pc.tC * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.0 / 6, 0.5), 1.0), 1.0);
+            invom = pc.invom * gy;
+            if (tiny) {
+                invden = pc.invden * __builtin_fma(-z, 1.0 - z, 1.0);
+                ex = pc.e * __builtin_fma(da, __builtin_fma(da, 0.5, 1.0), 1.0);
+                tC = pc.tC * __builtin_fma(w, __builtin_fma(w, 0.5, 1.0), 1.0);
+            } else {
+                invden = pc.invden * __builtin_fma(-z, __builtin_fma(-z, 1.0 - z, 1.0), 1.0);
+                ex = pc.e * __builtin_fma(da, __builtin_fma(da, __builtin_fma(da, 1.0 / 6, 0.5), 1.0), 1.0);
+                tC = pc.tC * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.0 / 6, 0.5), 1.0), 1.0);
+            }
             fv_check = fv_check && !pc.fv_quiet;
         }
     }
