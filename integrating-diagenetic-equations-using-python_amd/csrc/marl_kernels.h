@@ -49,7 +49,9 @@ __device__ __forceinline__ double nanmax(double a, double b) { return (a > b || 
 // ---------------------------------------------------------------------------------------------
 // Per-block stencil engine
 // ---------------------------------------------------------------------------------------------
-template <int BLK, int CPT>
+// REUSE = false: no transcendental cache (one-workgroup sweeps on coarse grids, where the stage displacements
+// are far outside the expansions' range and the cache would only cost registers).
+template <int BLK, int CPT, bool REUSE = true>
 struct StencilBlock {
     static constexpr int WIN = BLK * CPT;
     static constexpr int NSIDE = (CPT == 1) ? 1 : 2;
@@ -64,7 +66,7 @@ struct StencilBlock {
     int tid;
     int parity;
     unsigned first_mask, last_mask, zone_mask;  // bit c: the thread's c-th cell is global cell 0 / N-1 / in the dissolution zone
-    PointCache cache[CPT];       // transcendental values of the step's first evaluation (marl_math.h, TR_FILL / TR_REUSE)
+    PointCache cache[REUSE ? CPT : 1];  // transcendental values of the step's first evaluation (marl_math.h, TR_FILL / TR_REUSE)
     bool reuse_live = false;     // wave-uniform: the cache is filled and no stage of this step has fallen back yet
 
     // lds: LDS_DOUBLES doubles = edge exchange buffers followed by the log/exp tables (copied here; barrier inside).
@@ -129,7 +131,9 @@ struct StencilBlock {
                     for (int f = 0; f < NF; f++) um[f] = ghost_lower(C->bc[f], ys[c][f]);
                 }
             }
-            rhs_point<MODE>(ys[c], um, up, (zone_mask >> c) & 1u, K, C, T, k[c], aux[c], cache[c], reuse_live);
+            rhs_point<REUSE ? MODE : TR_PLAIN>(ys[c], um, up, (zone_mask >> c) & 1u, K, C, T, k[c], aux[c], cache[REUSE ? c : 0], reuse_live);
+            // one cell at a time: interleaving the cells' evaluations doubles the live temporaries (spills at CPT >= 2)
+            if constexpr (CPT > 1) __builtin_amdgcn_sched_barrier(0);
         }
     }
 };
@@ -637,8 +641,8 @@ __global__ void __launch_bounds__(256) rk45_control_kernel(const double* __restr
 // (RkDenseOutput, rk.py:560-574; w_2 = 0 because row 2 of P is zero).
 struct DenseWeights { double w[7]; };
 
-template <int BLK, int CPT, bool DENSE = false>
-__device__ __forceinline__ void dp45_attempt(StencilBlock<BLK, CPT>& sb, double h,
+template <int BLK, int CPT, bool DENSE = false, class SB = StencilBlock<BLK, CPT>>
+__device__ __forceinline__ void dp45_attempt(SB& sb, double h,
                                              const double (&y)[CPT][NF], const double (&k1)[CPT][NF],
                                              double (&yn)[CPT][NF], double (&k7)[CPT][NF], double (&esum)[CPT][NF],
                                              PointAux (&aux)[CPT], const DenseWeights& dw = DenseWeights{})
@@ -871,13 +875,14 @@ __global__ void __launch_bounds__(BLK) rk45_sweep_kernel(double* __restrict__ Y,
                                                          Rk45Ctrl* __restrict__ ctrls, int64_t N,
                                                          double* __restrict__ Yold, double* __restrict__ Fold)
 {
-    __shared__ double lds[StencilBlock<BLK, CPT>::LDS_DOUBLES + NQ * (BLK / 64)];
+    using SB = StencilBlock<BLK, CPT, false>;
+    __shared__ double lds[SB::LDS_DOUBLES + NQ * (BLK / 64)];
     __shared__ Rk45Ctrl sc;
     const DevConsts& C = consts[blockIdx.x];
     double* yg = Y + (int64_t)blockIdx.x * NF * N;
     Slab S = {N, 0, N, 0, N};
     const int64_t l0 = (int64_t)threadIdx.x * CPT;
-    StencilBlock<BLK, CPT> sb(lds, l0, consts + blockIdx.x);
+    SB sb(lds, l0, consts + blockIdx.x);
     if (threadIdx.x == 0) sc = ctrls[blockIdx.x];
     __syncthreads();
     if (sc.status != ST_RUNNING) return;
@@ -890,7 +895,7 @@ __global__ void __launch_bounds__(BLK) rk45_sweep_kernel(double* __restrict__ Y,
 
     while (true) {
         const double h = sc.h_try;
-        dp45_attempt<BLK, CPT>(sb, h, y, k1, yn, k7, esum, aux);
+        dp45_attempt<BLK, CPT, false, SB>(sb, h, y, k1, yn, k7, esum, aux);
         double q[NQ];
         monitors_init(q);
 #pragma unroll
@@ -901,7 +906,7 @@ __global__ void __launch_bounds__(BLK) rk45_sweep_kernel(double* __restrict__ Y,
                 monitors_accumulate(q, yn[c], aux[c].U, aux[c].W);
             }
         }
-        block_reduce<BLK, NQ, NQMIN>(q, lds + StencilBlock<BLK, CPT>::LDS_DOUBLES);
+        block_reduce<BLK, NQ, NQMIN>(q, lds + SB::LDS_DOUBLES);
         if (threadIdx.x == 0) rk45_finish_attempt(sc, q);
         __syncthreads();
         const int status = sc.status;
@@ -944,12 +949,13 @@ template <int BLK, int CPT>
 __global__ void __launch_bounds__(BLK) rk4_sweep_kernel(double* __restrict__ Y, const DevConsts* __restrict__ consts,
                                                         const double* __restrict__ dts, int64_t N, int64_t nsteps)
 {
-    __shared__ double lds[StencilBlock<BLK, CPT>::LDS_DOUBLES];
+    using SB = StencilBlock<BLK, CPT, false>;
+    __shared__ double lds[SB::LDS_DOUBLES];
     const DevConsts& C = consts[blockIdx.x];
     double* yg = Y + (int64_t)blockIdx.x * NF * N;
     Slab S = {N, 0, N, 0, N};
     const int64_t l0 = (int64_t)threadIdx.x * CPT;
-    StencilBlock<BLK, CPT> sb(lds, l0, consts + blockIdx.x);
+    SB sb(lds, l0, consts + blockIdx.x);
     const double dt = dts[blockIdx.x];
     const double h2 = 0.5 * dt, h6 = dt / 6.0;
     double y[CPT][NF], ys[CPT][NF], k[CPT][NF], acc[CPT][NF];

@@ -246,15 +246,20 @@ int marl_oracle_rk4(const marl_params *p, int64_t N, double *y, double dt, int64
     if (!buf) return -1;
     double *k = buf, *acc = buf + n, *ys = buf + 2 * n;
     const double h2 = 0.5 * dt, h6 = dt / 6.0;
+#ifdef _OPENMP
+#define ORC_PAR _Pragma("omp parallel for schedule(static)")
+#else
+#define ORC_PAR
+#endif
     for (int64_t s = 0; s < nsteps; s++) {
         orc_rhs(p, &c, N, y, k);
-        for (int64_t i = 0; i < n; i++) { acc[i] = k[i]; ys[i] = y[i] + h2 * k[i]; }
+        ORC_PAR for (int64_t i = 0; i < n; i++) { acc[i] = k[i]; ys[i] = y[i] + h2 * k[i]; }
         orc_rhs(p, &c, N, ys, k);
-        for (int64_t i = 0; i < n; i++) { acc[i] = acc[i] + 2.0 * k[i]; ys[i] = y[i] + h2 * k[i]; }
+        ORC_PAR for (int64_t i = 0; i < n; i++) { acc[i] = acc[i] + 2.0 * k[i]; ys[i] = y[i] + h2 * k[i]; }
         orc_rhs(p, &c, N, ys, k);
-        for (int64_t i = 0; i < n; i++) { acc[i] = acc[i] + 2.0 * k[i]; ys[i] = y[i] + dt * k[i]; }
+        ORC_PAR for (int64_t i = 0; i < n; i++) { acc[i] = acc[i] + 2.0 * k[i]; ys[i] = y[i] + dt * k[i]; }
         orc_rhs(p, &c, N, ys, k);
-        for (int64_t i = 0; i < n; i++) y[i] = y[i] + h6 * (acc[i] + k[i]);
+        ORC_PAR for (int64_t i = 0; i < n; i++) y[i] = y[i] + h6 * (acc[i] + k[i]);
     }
     free(buf);
     return 0;
@@ -266,7 +271,7 @@ int marl_oracle_rk4(const marl_params *p, int64_t N, double *y, double dt, int64
  * rk_step, :111-176 _step_impl, :377-407 tableau + dense output P, common.py:63-65 RMS norm,
  * ivp.py:654-723 driver incl. events and t_eval).
  * ---------------------------------------------------------------------------------------- */
-static const double DP_C[6] = {0, 1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1};
+static const double DP_C[6] __attribute__((unused)) = {0, 1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1};
 static const double DP_A[6][5] = {
     {0, 0, 0, 0, 0},
     {1.0 / 5, 0, 0, 0, 0},
