@@ -403,73 +403,6 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(CPT ==
 #endif
 }
 
-// Persistent form of the fused RK4 kernel: a fixed grid of resident workgroups, each walking over windows
-// blockIdx.x, blockIdx.x + gridDim.x, ...  The NEXT window's state is loaded while the current one is being
-// integrated (software prefetch), so HBM traffic overlaps the fp64 work instead of alternating with it (in the
-// one-window-per-block form all blocks of a dispatch round load, compute and store in lock-step), and the
-// log/exp tables and constants are set up once per block instead of once per window.
-#ifndef MARL_PERSIST_WAVES
-#define MARL_PERSIST_WAVES 4  // waves per SIMD the register allocator must leave room for (<= 128 VGPRs)
-#endif
-template <int BLK, int CPT, int LAYOUT, int NSTEPS>
-__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MARL_PERSIST_WAVES, 8))) rk4_persistent_kernel(const double* __restrict__ yin, double* __restrict__ yout,
-                                                             const DevConsts* __restrict__ consts, Slab S, double dt, int64_t nwin)
-{
-    constexpr int H = 4 * NSTEPS;
-    constexpr int WIN = BLK * CPT;
-    constexpr int V = WIN - 2 * H;
-    static_assert(V > 0, "window too small for the fused halo");
-    __shared__ double lds[StencilBlock<BLK, CPT>::LDS_DOUBLES];
-    const DevConsts& C = consts[0];
-    const int64_t tl = (int64_t)threadIdx.x * CPT - H;  // thread's first cell relative to the window's first OUTPUT cell
-    int64_t win = blockIdx.x;
-    if (win >= nwin) return;
-    int64_t l0 = S.out_lo + win * V + tl;
-    StencilBlock<BLK, CPT> sb(lds, l0 + S.goff, consts);
-    double y[CPT][NF], ys[CPT][NF], k[CPT][NF], acc[CPT][NF], ynext[CPT][NF];
-    PointAux aux[CPT];
-    load_cells<CPT, LAYOUT>(yin, l0, S, C, ynext);
-    const double h2 = 0.5 * dt, h6 = dt / 6.0;
-#define MARL_CELLS _Pragma("unroll") for (int c = 0; c < CPT; c++) _Pragma("unroll") for (int f = 0; f < NF; f++)
-#pragma unroll 1
-    while (true) {
-        MARL_CELLS y[c][f] = ynext[c][f];
-        const int64_t nxt = win + gridDim.x;
-        const int64_t l0n = S.out_lo + nxt * V + tl;
-#ifndef MARL_NO_PREFETCH
-        if (nxt < nwin) load_cells<CPT, LAYOUT>(yin, l0n, S, C, ynext);  // prefetch: consumed one iteration later
-#endif
-#pragma unroll 1
-        for (int step = 0; step < NSTEPS; step++) {
-            sb.template eval<TR_FILL>(y, k, aux);
-            MARL_CELLS { acc[c][f] = k[c][f]; ys[c][f] = y[c][f] + h2 * k[c][f]; }
-            sb.template eval<TR_REUSE>(ys, k, aux);
-            MARL_CELLS { acc[c][f] = acc[c][f] + 2.0 * k[c][f]; ys[c][f] = y[c][f] + h2 * k[c][f]; }
-            sb.template eval<TR_REUSE>(ys, k, aux);
-            MARL_CELLS { acc[c][f] = acc[c][f] + 2.0 * k[c][f]; ys[c][f] = y[c][f] + dt * k[c][f]; }
-            sb.template eval<TR_REUSE>(ys, k, aux);
-            MARL_CELLS y[c][f] = y[c][f] + h6 * (acc[c][f] + k[c][f]);
-        }
-#pragma unroll
-        for (int c = 0; c < CPT; c++) {
-            const int wi = threadIdx.x * CPT + c;
-            const int64_t l = l0 + c;
-            if (wi >= H && wi < WIN - H && l >= S.out_lo && l < S.out_hi) {
-#pragma unroll
-                for (int f = 0; f < NF; f++) yout[at<LAYOUT>(f, l, S.ld)] = y[c][f];
-            }
-        }
-        if (nxt >= nwin) break;
-        win = nxt;
-        l0 = l0n;
-        sb.set_window(l0 + S.goff);
-#ifdef MARL_NO_PREFETCH
-        load_cells<CPT, LAYOUT>(yin, l0, S, C, ynext);
-#endif
-    }
-#undef MARL_CELLS
-}
-
 // ---------------------------------------------------------------------------------------------
 // Dormand-Prince 5(4) coefficients: scipy/integrate/_ivp/rk.py:377-391
 // ---------------------------------------------------------------------------------------------

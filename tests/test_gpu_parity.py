@@ -453,3 +453,100 @@ def test_scipy_driven_radau_with_hip_rhs():
     assert covered == pytest.approx(13190.0)
     np.testing.assert_allclose(last, gold, rtol=0.1, atol=0.01)
     assert np.max(np.abs(last - gold)) < 1e-3      # the stub-hosted reference itself is within 7e-5 of this golden
+
+
+# ---------------------------------------------------------------------------------------------------------
+# edge cases the reference's formulas cover but its own tests do not
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("overrides", [{"m1": 0.0}, {"n2": 0.0, "m2": 0.0}, {"FV_switch": 0}])
+def test_rhs_unusual_parameters_against_oracle(oracle, overrides):
+    """Exponent 0 makes pow(0, e) = 1 instead of 0 (the kernels' general `generic_p0` combination); FV off."""
+    N = 96
+    p = scenario("default", N) | overrides
+    eq = make_model(p)
+    P = oracle.params_from_model(eq)
+    x = eq.Depths.axes_coords[0]
+    for kind in ("under", "over"):
+        y = eq.get_state(p["CAIni"], p["CCIni"], p["cCaIni"], p["cCO3Ini"], p["PhiIni"])
+        if kind == "over":
+            y[2] = 1.5 * (1 + 0.2 * np.sin(40 * x))
+            y[3] = 1.4 * (1 + 0.2 * np.cos(31 * x))
+        y[4] *= 1 + 0.1 * np.sin(25 * x)
+        y = y.ravel()
+        assert rel_to_max(eq.fun(0.0, y), oracle.rhs(P, N, y)) <= RHS_TOL, (overrides, kind)
+    dt = 0.05 * (eq.Depths.length / N) ** 2
+    assert rel_to_max(eq.integrate_rk4(y, dt, 10), oracle.rk4(P, N, y, dt, 10)) <= RUN_TOL
+    eq.close()
+
+
+@pytest.mark.parametrize("N,instances", [(200, 5), (300, 3), (513, 2), (64, 7)])
+def test_sweep_window_selection_for_odd_sizes(torch_cuda, oracle, N, instances):
+    """One-workgroup sweeps pick the smallest window >= N (256-, 512-, 1024-cell variants); cells beyond N idle."""
+    torch = torch_cuda
+    from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
+    base = scenario("A", N)
+    inst = [{"Phi0": 0.55 + 0.04 * i, "PhiIni": 0.5 + 0.03 * i, "PhiNR": 0.5 + 0.03 * i} for i in range(instances)]
+    eq = LMAHeureuxPorosityDiff.from_scenario(base, device=0, instances=inst)
+    y0 = np.stack([synthetic_state(base | i, N, amplitude=0.03) for i in inst])
+    dx2 = (eq.Depths.length / N) ** 2
+    yd = torch.from_numpy(y0).cuda()
+    res = eq.sweep_rk45_device(yd.data_ptr(), (0.0, 60 * dx2), 0.3 * dx2, 1e-4, 1e-6)
+    got = yd.cpu().numpy()
+    for b in range(instances):
+        yref, st, *_ = oracle.rk45(oracle.params_from_model(eq, b), N, y0[b], 0.0, 60 * dx2, 0.3 * dx2, 1e-4, 1e-6)
+        assert (res[b].status, res[b].n_accepted, res[b].n_rejected) == (0, st.n_accepted, st.n_rejected)
+        assert rel_to_max(got[b], yref) <= 1e-9
+    eq.close()
+
+
+@pytest.mark.parametrize("N", [12000, 40000])
+def test_stage_reuse_boundary_regime_against_oracle(torch_cuda, oracle, N):
+    """Grid sizes where the stage-to-stage expansions (marl_math.h) are partly in and partly out of range:
+    some waves expand, others fall back to the full evaluation - the result must not care."""
+    torch = torch_cuda
+    p = scenario("default", N)
+    eq = make_model(p)
+    eq.use_stream(torch.cuda.current_stream().cuda_stream)
+    y = synthetic_state(p, N, amplitude=0.05)
+    dx2 = (eq.Depths.length / N) ** 2
+    ref = oracle.rk4(oracle.params_from_model(eq), N, y, 0.25 * dx2, 12, omp=True)
+    yd = torch.from_numpy(y).cuda()
+    eq.integrate_rk4_device(yd.data_ptr(), 0.25 * dx2, 12)
+    torch.cuda.synchronize()
+    assert rel_to_max(yd.cpu().numpy(), ref) <= RUN_TOL
+    yref, st, *_ = oracle.rk45(oracle.params_from_model(eq), N, y, 0.0, 30 * dx2, 0.5 * dx2, 1e-5, 1e-7, omp=True)
+    yd = torch.from_numpy(y).cuda()
+    res = eq.integrate_rk45_device(yd.data_ptr(), (0.0, 30 * dx2), 0.5 * dx2, 1e-5, 1e-7)
+    assert (res.status, res.n_accepted, res.n_rejected) == (0, st.n_accepted, st.n_rejected)
+    assert rel_to_max(yd.cpu().numpy(), yref) <= RUN_TOL
+    eq.close()
+
+
+def test_api_errors_are_reported_not_swallowed():
+    from marlpde_amd._abi import MarlError
+    p = scenario("default", 200)
+    eq = make_model(p)
+    y = synthetic_state(p, 200)
+    with pytest.raises(MarlError, match="unknown option"):
+        eq.set_option("no_such_knob", 1)
+    with pytest.raises(MarlError, match="first_step"):
+        eq.integrate_rk45(y, (0.0, 1e-3), 1.0, 1e-3, 1e-3)          # scipy: "`first_step` exceeds bounds"
+    with pytest.raises(MarlError, match="t_eval"):
+        eq.integrate_rk45(y, (0.0, 1e-3), 1e-6, 1e-3, 1e-3, t_eval=[0.0, 2e-3])
+    with pytest.raises(ValueError, match="state has"):
+        eq.fun(0.0, y[:-1])
+    eq.close()
+
+
+def test_integrate_equations_stores_results_like_the_reference(tmp_path):
+    """Dataset names of the result file: solutions (5, N, n_t), times, event_0..6 (marlpde/Evolve_scenario.py:172-178)."""
+    from dataclasses import asdict, replace
+    from marlpde_amd.Evolve_scenario import integrate_equations
+    from marlpde_amd.parameters import Solver, Tracker
+    sol = asdict(replace(Solver(), method="RK45", t_span=(0, 2e-3)))
+    trk = asdict(Tracker()) | {"t_eval": np.linspace(0, 2e-3, 3)}
+    last, covered, depths, Xstar, folder = integrate_equations(sol, trk, scenario("A"), results_root=str(tmp_path) + "/", verbose=False)
+    z = np.load(folder + "LMAHeureuxPorosityDiff.npz")
+    assert z["solutions"].shape == (5, 200, 3) and np.array_equal(z["times"], trk["t_eval"])
+    assert all(f"event_{i}" in z for i in range(7)) and float(z["attr_Phi0"]) == 0.6
+    assert np.array_equal(z["solutions"][:, :, -1], last) and covered == pytest.approx(13190.0 * 2e-3)
