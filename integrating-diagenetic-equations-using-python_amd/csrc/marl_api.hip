@@ -105,6 +105,7 @@ static void derive_consts(const marl_params& p, int64_t N, DevConsts& c, double 
     k.pe_smax = k.pe_cCa > k.pe_cCO3 ? k.pe_cCa : k.pe_cCO3;
     k.Dal = k.Da * k.lambda_;
     k.rr10 = 10.0 * k.rhorat;
+    k.dPhi_dx2 = k.dPhi * k.inv_dx2;
     const double bc[NF] = {p.CA0, p.CC0, p.cCa0, p.cCO30, p.Phi0};
     for (int f = 0; f < NF; f++) c.bc[f] = bc[f];
     c.N = N;

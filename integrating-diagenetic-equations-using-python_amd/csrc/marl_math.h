@@ -44,6 +44,7 @@ struct HotConsts {
     double pe_smax;                  // max(pe_cCa, pe_cCO3)
     double Dal;                      // Da * lambda_
     double rr10;                     // 10 * rhorat
+    double dPhi_dx2;                 // dPhi / dx^2
     int32_t fv;                      // FV_switch
     int32_t generic_p0;              // some exponent <= 0, i.e. some pow(0, e) != 0: take the general combination
 };
@@ -306,13 +307,6 @@ __device__ __forceinline__ void rhs_point(const double (&uc)[NF], const double (
     aux.U = U;
     aux.W = W;
 
-    // ---- one-sided differences (x dx): back = u - u[i-1], forw = u[i+1] - u   (:372-384)
-    const double a_b = CA - um[0], a_f = up[0] - CA;
-    const double k_b = CC - um[1], k_f = up[1] - CC;
-    const double c_b = c - um[2], c_f = up[2] - c;
-    const double o_b = o - um[3], o_f = up[3] - o;
-    const double p_b = Phi - um[4], p_f = up[4] - Phi;
-
     // ---- reaction terms (:479-493).  Of each clamp pair (min(x,1), max(x,1)) one power has base exactly 0
     // and the other has base |x - 1|; with positive exponents the zero-base member vanishes.
     double tA = O3 - O3;                        // 0, or NaN for a non-finite O3 (keeps the reference's NaN visible)
@@ -328,13 +322,16 @@ __device__ __forceinline__ void rhs_point(const double (&uc)[NF], const double (
     }
     const double DA = K.Da * (CA * tA);          // Da coA
     const double DC = K.Dal * (CC * tC);         // Da lambda coC
-    const double DaR = omPhi * (DA - DC);        // Da (1-Phi) (coA - lambda coC)
+    const double DmD = DA - DC;
+    const double DaR = omPhi * DmD;              // Da (1-Phi) (coA - lambda coC)
 
-    // ---- solids: upwinded gradient (:418-423) and rates (:498-503)
+    // ---- solids: upwinded one-sided difference (:372-384, :418-423) and rates (:498-503).
+    //   U > 0: -U (u - u[i-1])/dx;  else: -U (u[i+1] - u)/dx = -|U| (u - u[i+1])/dx   -> one difference against
+    //   the upwind neighbour;  (1-CA) DA + CA DC = DA - CA (DA - DC);  CC DA + (1-CC) DC = DC + CC (DA - DC).
     const bool upw = U > 0.0;
-    const double Ux = U * K.inv_dx;
-    r[0] = __builtin_fma(-Ux, upw ? a_b : a_f, -__builtin_fma(CA, DC, (1.0 - CA) * DA));
-    r[1] = __builtin_fma(-Ux, upw ? k_b : k_f, __builtin_fma(CC, DA, (1.0 - CC) * DC));
+    const double Ux = fabs(U * K.inv_dx);
+    r[0] = __builtin_fma(-Ux, CA - (upw ? um[0] : up[0]), __builtin_fma(CA, DmD, -DA));
+    r[1] = __builtin_fma(-Ux, CC - (upw ? um[1] : up[1]), __builtin_fma(CC, DmD, DC));
 
     // ---- solutes and porosity.  Fiadeiro-Veronis weights (:433-462) all vanish when every |Pe| < PECLET_MIN
     // (always on fine grids): then the weighted gradient 0.5*((1-s) forw + (1+s) back) is the central one.
@@ -348,8 +345,14 @@ __device__ __forceinline__ void rhs_point(const double (&uc)[NF], const double (
         pc.fv_quiet = true;  // FV_switch off
     }
     const double h1x = (Phi * invden) * K.inv_dx2;                  // Phi/den / dx^2
-    const double h2f = (2.0 + den) * (invden * invden);             // (2+den)/den^2
+    const double h2f = invden * __builtin_fma(2.0, invden, 1.0);    // (2+den)/den^2
     const double q = __builtin_fma(rF, __builtin_fma(2.0, Phi, 10.0), -K.rr10);  // rhorat (2 Phi F + 10 (F-1))  (:495)
+    // one-sided differences (x dx): back = u - u[i-1], forw = u[i+1] - u (:372-384) - both exact for smooth fields
+    // (Sterbenz), so forw - back is a second difference WITHOUT the 1-ulp-of-u noise of u[i-1] - 2u + u[i+1]
+    // (which, times 1/dx^2, is what limits the reference's own RHS to ~1e-10 relative on fine grids).
+    const double c_b = c - um[2], c_f = up[2] - c;
+    const double o_b = o - um[3], o_f = up[3] - o;
+    const double p_b = Phi - um[4], p_f = up[4] - Phi;
     const double p_d = p_f - p_b, c_d = c_f - c_b, o_d = o_f - o_b;
     double pg, cg, og;  // gradients (already divided by dx)
     if (!fv_active) {
@@ -368,7 +371,7 @@ __device__ __forceinline__ void rhs_point(const double (&uc)[NF], const double (
     r[2] = __builtin_fma(-W, cg, __builtin_fma(DaR, K.delta - c, Hc) * invPhi);   // :506-509
     r[3] = __builtin_fma(-W, og, __builtin_fma(DaR, K.delta - o, Ho) * invPhi);   // :512-515
     // -(dWdx Phi + W Phi') with dWdx = -q Phi'  ->  -Phi' (W - Phi q)             // :495, :518-520
-    r[4] = __builtin_fma(-pg, __builtin_fma(-Phi, q, W), __builtin_fma(K.dPhi * K.inv_dx2, p_d, DaR));
+    r[4] = __builtin_fma(-pg, __builtin_fma(-Phi, q, W), __builtin_fma(K.dPhi_dx2, p_d, DaR));
 }
 #pragma clang diagnostic pop
 
