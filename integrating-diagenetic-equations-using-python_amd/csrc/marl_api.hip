@@ -97,7 +97,9 @@ static void derive_consts(const marl_params& p, int64_t N, DevConsts& c, double 
     k.m1 = p.m1; k.m2 = p.m2; k.n1 = p.n1; k.n2 = p.n2;
     c.p0_m1 = std::pow(0.0, p.m1); c.p0_m2 = std::pow(0.0, p.m2);
     c.p0_n1 = std::pow(0.0, p.n1); c.p0_n2 = std::pow(0.0, p.n2);
-    k.generic_p0 = (c.p0_m1 != 0 || c.p0_m2 != 0 || c.p0_n1 != 0 || c.p0_n2 != 0) ? 1 : 0;
+    // exponents <= 0: pow(0, e) != 0, the clamp pairs need the general combination; exponents < 1: the stage-reuse
+    // expansions' range check (|u| <= |n u|) does not hold - both take the general, cache-less evaluation
+    k.generic_p0 = (c.p0_m1 != 0 || c.p0_m2 != 0 || c.p0_n1 != 0 || c.p0_n2 != 0 || !(p.m1 >= 1) || !(p.m2 >= 1) || !(p.n1 >= 1) || !(p.n2 >= 1)) ? 1 : 0;
     k.lambda_ = p.k3 / p.k2;
     k.Da = p.k2 * p.Tstar;
     k.delta = p.rhos / (p.muA * std::sqrt(p.KC));

@@ -50,14 +50,17 @@ __device__ __forceinline__ double nanmax(double a, double b) { return (a > b || 
 // Per-block stencil engine
 // ---------------------------------------------------------------------------------------------
 // REUSE = false: no transcendental cache (one-workgroup sweeps on coarse grids, where the stage displacements
-// are far outside the expansions' range and the cache would only cost registers).
+// are far outside the expansions' range).  The cache (marl_math.h, PointCache) also needs its LDS slots to fit
+// the 64 KB a workgroup may declare: wide variants (512 threads, several cells per thread) run without it.
 template <int BLK, int CPT, bool REUSE = true>
 struct StencilBlock {
     static constexpr int WIN = BLK * CPT;
     static constexpr int NSIDE = (CPT == 1) ? 1 : 2;
-    static constexpr int LDS_DOUBLES = 2 * NSIDE * NF * BLK + TABLE_DOUBLES;  // edges [parity][side][field][thread] + tables
-
-    static constexpr int EDGE_DOUBLES = 2 * NSIDE * NF * BLK;
+    static constexpr int EDGE_DOUBLES = 2 * NSIDE * NF * BLK;       // edges [parity][side][field][thread]
+    static constexpr bool CACHE_LDS = PC_LDS_SLOTS > 0;
+    static constexpr bool CACHE = REUSE && (EDGE_DOUBLES + TABLE_DOUBLES + PC_LDS_SLOTS * WIN) * 8 <= 60 * 1024;
+    static constexpr int CACHE_DOUBLES = CACHE ? PC_LDS_SLOTS * WIN : 0;
+    static constexpr int LDS_DOUBLES = EDGE_DOUBLES + TABLE_DOUBLES + CACHE_DOUBLES;  // edges, log/exp tables, cache slots [slot][cell][thread]
 
     double* lds;
     Tables T;
@@ -66,8 +69,8 @@ struct StencilBlock {
     int tid;
     int parity;
     unsigned first_mask, last_mask, zone_mask;  // bit c: the thread's c-th cell is global cell 0 / N-1 / in the dissolution zone
-    PointCache cache[REUSE ? CPT : 1];  // transcendental values of the step's first evaluation (marl_math.h, TR_FILL / TR_REUSE)
-    bool reuse_live = false;     // wave-uniform: the cache is filled and no stage of this step has fallen back yet
+    PointCache<(CACHE && CACHE_LDS) ? WIN : 0> cache[CACHE ? CPT : 1];  // centre of the transcendental expansions (TR_FILL / TR_REUSE / TR_AUTO)
+    bool reuse_live[CPT] = {};   // wave-uniform, per cell: the centre is filled and no evaluation since has fallen out of range
 
     // lds: LDS_DOUBLES doubles = edge exchange buffers followed by the log/exp tables (copied here; barrier inside).
     // g0: global index of this thread's first cell.
@@ -75,9 +78,13 @@ struct StencilBlock {
         : lds(lds_), T(load_tables(lds_ + EDGE_DOUBLES, BLK)), K(load_hot(c)), C(c), tid(threadIdx.x), parity(0)
     {
         set_window(g0);
+        if constexpr (CACHE && CACHE_LDS) {
+#pragma unroll
+            for (int c = 0; c < CPT; c++) cache[c].s = lds_ + EDGE_DOUBLES + TABLE_DOUBLES + c * BLK + tid;
+        }
     }
 
-    // (Re)position the window: persistent kernels walk one block over several windows.
+    // (Re)position the window.
     __device__ __forceinline__ void set_window(int64_t g0)
     {
         const int64_t N = C->N, mlo = C->mask_lo, mhi = C->mask_hi;
@@ -91,8 +98,10 @@ struct StencilBlock {
         }
     }
 
-    // k[c] = RHS(stage state ys) for the thread's CPT cells.  Contains exactly one __syncthreads().
-    // MODE: TR_FILL for the first evaluation of a step / attempt, TR_REUSE for the following ones, TR_PLAIN otherwise.
+    // k[c] = RHS(stage state ys) for the thread's CPT cells.  Contains exactly one __syncthreads(): the own-cell phase
+    // of the evaluation (marl_math.h, point_local) runs between the edge writes and the barrier, the stencil phase
+    // after it - the neighbour values are not live during the transcendental part.
+    // MODE: see marl_math.h (TR_FILL / TR_AUTO for a first stage, TR_REUSE for the following ones, TR_PLAIN otherwise).
     template <int MODE = TR_PLAIN>
     __device__ __forceinline__ void eval(const double (&ys)[CPT][NF], double (&k)[CPT][NF], PointAux (&aux)[CPT])
     {
@@ -101,6 +110,13 @@ struct StencilBlock {
         for (int f = 0; f < NF; f++) {
             e[f * BLK + tid] = ys[0][f];
             if constexpr (CPT > 1) e[(NF + f) * BLK + tid] = ys[CPT - 1][f];
+        }
+        PointLocal pl[CPT];
+#pragma unroll
+        for (int c = 0; c < CPT; c++) {
+            point_local<CACHE ? MODE : TR_PLAIN>(ys[c], (zone_mask >> c) & 1u, K, C, T, pl[c], aux[c], cache[CACHE ? c : 0], reuse_live[c]);
+            // one cell at a time: interleaving the cells' evaluations doubles the live temporaries (spills at CPT >= 2)
+            if constexpr (CPT > 1) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
         const int tl = tid > 0 ? tid - 1 : 0;
@@ -131,9 +147,7 @@ struct StencilBlock {
                     for (int f = 0; f < NF; f++) um[f] = ghost_lower(C->bc[f], ys[c][f]);
                 }
             }
-            rhs_point<REUSE ? MODE : TR_PLAIN>(ys[c], um, up, (zone_mask >> c) & 1u, K, C, T, k[c], aux[c], cache[REUSE ? c : 0], reuse_live);
-            // one cell at a time: interleaving the cells' evaluations doubles the live temporaries (spills at CPT >= 2)
-            if constexpr (CPT > 1) __builtin_amdgcn_sched_barrier(0);
+            point_rates(ys[c], um, up, K, T, pl[c], k[c]);
         }
     }
 };
@@ -200,7 +214,7 @@ __global__ void __launch_bounds__(256) rhs_kernel(const double* __restrict__ y, 
 #pragma unroll
     for (int f = 0; f < NF; f++) up[f] = (g < C.N - 1) ? y[at<LAYOUT>(f, l + 1, S.ld)] : ghost_upper(f, uc[f], um[f]);
     const HotConsts K = load_hot(&C);
-    PointCache pc;
+    PointCache<0> pc;
     bool live = false;
     rhs_point<TR_PLAIN>(uc, um, up, g >= C.mask_lo && g < C.mask_hi, K, &C, T, r, aux, pc, live);
 #pragma unroll
@@ -337,8 +351,8 @@ __device__ __forceinline__ void load_cells(const double* __restrict__ y, int64_t
 #ifdef MARL_LAB_CLOCK  // kernel-lab diagnostic build only: in-kernel shader clock (s_memtime) vs 100 MHz s_memrealtime
 __device__ unsigned long long marl_lab_clock[3 * 16384];
 #endif
-// One cell per thread needs ~133 VGPRs; asking for 4 waves per SIMD (<= 128) costs 6 spilled registers and buys
-// +4 % (profiles/r01_lab_*.log).  Variants with more cells per thread keep the compiler's own choice.
+// One cell per thread: 4 waves per SIMD (<= 128 VGPRs; 4 workgroups of 256 share the CU's 160 KB of LDS).
+// Variants with more cells per thread keep the compiler's own choice.
 template <int BLK, int CPT, int LAYOUT, int NSTEPS>
 __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(CPT == 1 ? 4 : 1, 8))) rk4_fused_kernel(const double* __restrict__ yin, double* __restrict__ yout,
                                                         const DevConsts* __restrict__ consts, Slab S, double dt)
@@ -363,7 +377,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(CPT ==
 
 #pragma unroll 1
     for (int step = 0; step < NSTEPS; step++) {
-        sb.template eval<TR_FILL>(y, k, aux);
+        sb.template eval<TR_AUTO>(y, k, aux);   // the centre of the expansions survives from step to step
 #pragma unroll
         for (int c = 0; c < CPT; c++)
 #pragma unroll

@@ -178,87 +178,124 @@ struct PointAux {
     double U, W;  // by-products needed by the monitors zeros_U / zeros_W (LHeureux_model.py:567-593)
 };
 
-// Transcendental reuse across the stages of one RK step.  The stage states of an explicit step on a fine grid
-// differ from the step's first state by dt*rate - relatively 1e-10 at N = 2^20, 1e-6 at N = 65 536 - so
-// log(Phi), the reciprocals, exp(10 - 10/Phi) and the saturation power of a LATER stage are given to full fp64
-// accuracy by 3rd-order expansions around the values the FIRST evaluation computed (truncation < 1e-17 while
-// every expansion variable is below REUSE_LIMIT).  The first evaluation fills the cache (TR_FILL); later ones
-// (TR_REUSE) check the variables and fall back to the full evaluation - wave-uniformly - when any lane is out
-// of range (coarse grids, large steps, non-finite states); after one fall-back the remaining stages of that step
-// skip the check.  TR_PLAIN: no cache (stand-alone RHS).
-enum : int { TR_PLAIN = 0, TR_FILL = 1, TR_REUSE = 2 };
+// Transcendental reuse across Runge-Kutta stages (and steps).  The stage states of an explicit step on a fine grid
+// differ from the step's first state by dt*rate - relatively 1e-10 at N = 2^20, 1e-6 at N = 65 536 - so log(Phi),
+// the reciprocals, exp(10 - 10/Phi) and the calcite saturation power of a LATER evaluation are given to full fp64
+// accuracy by 2nd/3rd-order expansions around the values an EARLIER evaluation (the "centre") computed; truncation
+// < 1e-17 relative while every expansion variable is below REUSE_LIMIT.  Modes of one evaluation:
+//   TR_PLAIN  no cache (stand-alone RHS, one-workgroup sweeps on coarse grids)
+//   TR_FILL   full evaluation; becomes the centre
+//   TR_REUSE  expand around the centre if it is `live`; any lane of the wave out of range (coarse grid, large step,
+//             non-finite state) -> the whole wave evaluates in full and stops trying (`live` = false)
+//   TR_AUTO   as TR_REUSE, but a wave that falls back becomes the new centre (first stage of every step: the centre
+//             then survives from step to step inside one launch and is renewed only when it has drifted out of range)
+// Storage: what the range check needs sits in registers; of the six cached values the last MARL_CACHE_LDS_SLOTS sit
+// in LDS (one slot column per cell, STRIDE doubles between slots).  All in registers, a centre that lives across the
+// step loop spills at 4 waves per SIMD (scratch reloads in every stage: -25 %); all in LDS, the extra ds_reads
+// cost more than they save (the neighbour exchange already loads the LDS pipe) - profiles/r01_lab_cache_placement.log.
+enum : int { TR_PLAIN = 0, TR_FILL = 1, TR_REUSE = 2, TR_AUTO = 3 };
 constexpr double REUSE_LIMIT = 5e-5;   // 3rd-order expansions: truncation x^4 < 1e-17
 constexpr double REUSE_TINY = 2e-6;    // below this the 3rd-order terms themselves are < 1e-17: 2nd order suffices
 
+#ifndef MARL_CACHE_LDS_SLOTS   // how many of the slots (counted from the end of the list) live in LDS; the rest in registers
+#define MARL_CACHE_LDS_SLOTS 4
+#endif
+// slots: 1/Phi, 1/(1-Phi), 1/den, 1/(O2-1), exp(10-10/Phi), calcite term
+enum : int { PC_INVPHI, PC_INVOM, PC_INVDEN, PC_IB, PC_E, PC_TC, PC_SLOTS };
+constexpr int PC_FIRST_LDS = PC_SLOTS - (MARL_CACHE_LDS_SLOTS < PC_SLOTS ? MARL_CACHE_LDS_SLOTS : PC_SLOTS);
+constexpr int PC_LDS_SLOTS = PC_SLOTS - PC_FIRST_LDS;
+
+template <int STRIDE>   // doubles between the LDS slots of one cell; 0: every slot in registers
 struct PointCache {
-    double Phi, invPhi, invom, L, invden, e;  // Phi, 1/Phi, 1/(1-Phi), log Phi, 1/den, exp(10 - 10/Phi)
-    double O2, ib, n, tC;                     // c*o, 1/(c*o - 1), the exponent in use, coefficient * |c*o - 1|^n
-    bool fv_quiet;                            // all three Peclet numbers were < 0.9 PECLET_MIN at the first evaluation
+    static constexpr int FIRST_LDS = STRIDE > 0 ? PC_FIRST_LDS : PC_SLOTS;
+    // centre: Phi, O2 = cCa*cCO3; cPhi bounds every porosity expansion variable per unit |Phi - centre|;
+    // nib = n/(O2-1): first-order variable of the calcite saturation power (n: the exponent in use)
+    double Phi, O2, cPhi, nib;
+    double* s;                       // this cell's LDS slots (slot j at s[(j - FIRST_LDS) * STRIDE])
+    double v[FIRST_LDS > 0 ? FIRST_LDS : 1];
+    bool fv_quiet;                   // all three Peclet numbers were < 0.9 PECLET_MIN at the centre
+    __device__ __forceinline__ double get(int j) const { return j < FIRST_LDS ? v[j] : s[(j - FIRST_LDS) * STRIDE]; }
+    __device__ __forceinline__ void set(int j, double x) { if (j < FIRST_LDS) v[j] = x; else s[(j - FIRST_LDS) * STRIDE] = x; }
 };
 
-// uc/um/up: values at cell i, i-1, i+1 (ghosts already substituted).  in_mask: cell inside the
-// dissolution zone.  K: hot constants (registers); C: the instance's full constant block (cold parts are
-// read from memory only on rare paths).  r: the five rates (LHeureux_model.py:498-520).
+// One RHS evaluation of a cell is split in two phases, so that the neighbour values (10 doubles) are not held in
+// registers while the transcendental part runs, and so that a stencil kernel can do the own-cell work BEFORE the
+// barrier of its neighbour exchange:
+//   point_local  - everything that depends on the cell's own five values (porosity functions, velocities, reaction
+//                  terms, Peclet test): results in PointLocal
+//   point_rates  - the stencil part: differences against u[i-1], u[i+1] and the five rates
+struct PointLocal {
+    double Ux, R0, R1;          // |U|/dx and the reaction parts of the two solid rates
+    double W, invPhi, G2, G3;   // solutes: advection velocity, 1/Phi, Da (1-Phi)(coA - lambda coC)(delta - c)/Phi
+    double h1x, h2f;            // Phi/den/dx^2, (2+den)/den^2  (common_helper1/2, :470-473)
+    double Q4, DaR;             // porosity: W - Phi dW/dPhi-part (:495), Da (1-Phi)(coA - lambda coC)
+    double Wd;                  // W den (Peclet numbers; only read when fv_active)
+    bool upw, fv_active;
+};
+
+// uc: the cell's five values.  in_mask: cell inside the dissolution zone.  K: hot constants (registers); C: the
+// instance's full constant block (cold parts are read from memory only on rare paths).
 #pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wsometimes-uninitialized"  // den ... tC are set on exactly one of the two paths below
-template <int MODE>
-__device__ __forceinline__ void rhs_point(const double (&uc)[NF], const double (&um)[NF], const double (&up)[NF],
-                                          bool in_mask, const HotConsts& K, const DevConsts* __restrict__ C,
-                                          const Tables& T, double (&r)[NF], PointAux& aux, PointCache& pc, bool& live)
+#pragma clang diagnostic ignored "-Wsometimes-uninitialized"  // den ... tA are set on exactly one of the two paths below
+template <int MODE, int STRIDE>
+__device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask, const HotConsts& K, const DevConsts* __restrict__ C,
+                                            const Tables& T, PointLocal& pl, PointAux& aux, PointCache<STRIDE>& pc, bool& live)
 {
 #ifdef MARL_ABLATE_CORE  // kernel-lab builds only: the skeleton (loads, LDS exchange, barriers, RK combinations)
-    for (int f = 0; f < NF; f++) r[f] = (up[f] - um[f]) * K.hdx * 1e-9;
     aux.U = aux.W = 0.0;
     return;
 #endif
     const double CA = uc[0], CC = uc[1], c = uc[2], o = uc[3], Phi = uc[4];
     const double omPhi = 1.0 - Phi;
     const double O2 = c * o;
-    const double O3 = O2 * K.KRat;
-    const bool under = O3 < 1.0;
 
-    // ---- porosity-only quantities (:414-429) and the calcite saturation term (:490-491):
-    //      tC = (O2-1)^n1 if O2 > 1 else -nu2 (1-O2)^n2   (one power per clamp pair, see below)
-    double den, invPhi, invom, invden, ex, tC;
+    // ---- porosity-only quantities (:414-429) and the saturation terms (:479-493):
+    //      tC = (O2-1)^n1 if O2 > 1 else -nu2 (1-O2)^n2 ;  tA = (1-O3)^m2 mask if O3 < 1 else -nu1 (O3-1)^m1
+    //      (of each clamp pair (min(x,1), max(x,1)) one power has base exactly 0 and the other has base |x - 1|;
+    //      with positive exponents the zero-base member vanishes)
+    double den, invPhi, invom, invden, ex, tC, tA;
     bool fv_check = K.fv != 0;
     bool reuse = false;
-    if constexpr (MODE == TR_FILL) live = true;
-    if (MODE == TR_REUSE && live) {   // `live` (wave-uniform): no earlier stage of this step fell back
-        const double d = Phi - pc.Phi;
-        const double x = d * pc.invPhi, y = d * pc.invom, u = (O2 - pc.O2) * pc.ib;
-        // first-order estimates of the other expansion variables decide the tier (exact values follow)
-        const double big = fmax(fmax(fmax(fabs(x), fabs(y)), fmax(fabs(u * pc.n), 12.0 * fabs(x * pc.invPhi))), 2.2 * fabs(x * pc.invden));
-        reuse = __builtin_amdgcn_ballot_w64(!(big < REUSE_LIMIT)) == 0;   // NaN compares false -> falls back
-        live = reuse;   // out of range once (coarse grid / large step): stop trying for the rest of this step
+    if constexpr (MODE == TR_FILL) live = false;
+    if ((MODE == TR_REUSE || MODE == TR_AUTO) && live) {   // `live` is wave-uniform
+        const double d = Phi - pc.Phi, dO = O2 - pc.O2;
+        const double v = dO * pc.nib;
+        // every expansion variable below is bounded by this sum (NaN compares false -> falls back)
+        const double big = __builtin_fma(fabs(d), pc.cPhi, fabs(v));
+        reuse = __builtin_amdgcn_ballot_w64(!(big < REUSE_LIMIT)) == 0;
+        live = reuse;
         if (reuse) {
             const bool tiny = __builtin_amdgcn_ballot_w64(!(big < REUSE_TINY)) == 0;
+            const double invPhi0 = pc.get(PC_INVPHI), invom0 = pc.get(PC_INVOM), invden0 = pc.get(PC_INVDEN), ib0 = pc.get(PC_IB);
+            const double e0 = pc.get(PC_E), tC0 = pc.get(PC_TC);
+            const double x = d * invPhi0, y = d * invom0, u = dO * ib0;
             double l1p, ip, w, gy;
             if (tiny) {
                 l1p = x * __builtin_fma(x, -0.5, 1.0);                                    // log1p(x)
-                ip = pc.invPhi * __builtin_fma(-x, 1.0 - x, 1.0);                         // 1/(Phi0 (1+x))
-                w = pc.n * (u * __builtin_fma(u, -0.5, 1.0));                             // n log1p(u)
+                ip = invPhi0 * __builtin_fma(-x, 1.0 - x, 1.0);                           // 1/(Phi0 (1+x))
+                w = v * __builtin_fma(u, -0.5, 1.0);                                      // n log1p(u)
                 gy = __builtin_fma(y, 1.0 + y, 1.0);                                      // 1/(1-y)
             } else {
                 l1p = x * __builtin_fma(x, __builtin_fma(x, 1.0 / 3, -0.5), 1.0);
-                ip = pc.invPhi * __builtin_fma(-x, __builtin_fma(-x, 1.0 - x, 1.0), 1.0);
-                w = pc.n * (u * __builtin_fma(u, __builtin_fma(u, 1.0 / 3, -0.5), 1.0));
+                ip = invPhi0 * __builtin_fma(-x, __builtin_fma(-x, 1.0 - x, 1.0), 1.0);
+                w = v * __builtin_fma(u, __builtin_fma(u, 1.0 / 3, -0.5), 1.0);
                 gy = __builtin_fma(y, __builtin_fma(y, 1.0 + y, 1.0), 1.0);
             }
-            const double z = -2.0 * l1p * pc.invden;                                      // (den - den0)/den0
-            const double da = -10.0 * (ip - pc.invPhi);                                   // change of 10 - 10/Phi
+            const double z = -2.0 * l1p * invden0;                                        // (den - den0)/den0
+            const double da = -10.0 * (ip - invPhi0);                                     // change of 10 - 10/Phi
             invPhi = ip;
-            den = __builtin_fma(-2.0, pc.L + l1p, 1.0);
-            invom = pc.invom * gy;
+            invom = invom0 * gy;
             if (tiny) {
-                invden = pc.invden * __builtin_fma(-z, 1.0 - z, 1.0);
-                ex = pc.e * __builtin_fma(da, __builtin_fma(da, 0.5, 1.0), 1.0);
-                tC = pc.tC * __builtin_fma(w, __builtin_fma(w, 0.5, 1.0), 1.0);
+                invden = invden0 * __builtin_fma(-z, 1.0 - z, 1.0);
+                ex = e0 * __builtin_fma(da, __builtin_fma(da, 0.5, 1.0), 1.0);
+                tC = tC0 * __builtin_fma(w, __builtin_fma(w, 0.5, 1.0), 1.0);
             } else {
-                invden = pc.invden * __builtin_fma(-z, __builtin_fma(-z, 1.0 - z, 1.0), 1.0);
-                ex = pc.e * __builtin_fma(da, __builtin_fma(da, __builtin_fma(da, 1.0 / 6, 0.5), 1.0), 1.0);
-                tC = pc.tC * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.0 / 6, 0.5), 1.0), 1.0);
+                invden = invden0 * __builtin_fma(-z, __builtin_fma(-z, 1.0 - z, 1.0), 1.0);
+                ex = e0 * __builtin_fma(da, __builtin_fma(da, __builtin_fma(da, 1.0 / 6, 0.5), 1.0), 1.0);
+                tC = tC0 * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.0 / 6, 0.5), 1.0), 1.0);
             }
             fv_check = fv_check && !pc.fv_quiet;
+            if (fv_check) den = rcp_nr(invden);   // only the Peclet numbers need den itself
         }
     }
     if (!reuse) {
@@ -290,13 +327,38 @@ __device__ __forceinline__ void rhs_point(const double (&uc)[NF], const double (
 #endif
         tC = (over ? 1.0 : -K.nu2) * pwC;
         if (K.generic_p0) {  // an exponent <= 0: pow(0, e) is 1 or inf instead of 0 (rare; constants from memory)
+            asm volatile("");  // keep this a (uniform) branch: if-converted, its arithmetic would run on every evaluation
             const double y1 = C->p0_n1, y2 = C->p0_n2;
             const double pcw = (O2 == 1.0) ? (over ? y1 : y2) : pwC;
             tC = over ? pcw - K.nu2 * y2 : y1 - K.nu2 * pcw;
         }
-        if constexpr (MODE == TR_FILL) {
-            pc.Phi = Phi; pc.invPhi = invPhi; pc.invom = invom; pc.L = L; pc.invden = invden; pc.e = ex;
-            pc.O2 = O2; pc.ib = K.generic_p0 ? __builtin_nan("") : rcp_nr(O2 - 1.0); pc.n = nsel; pc.tC = tC;
+        if constexpr (MODE == TR_FILL || MODE == TR_AUTO) {
+            // generic_p0 (an exponent < 1 or <= 0: the clamp-pair shortcut / the bound |u| <= |n u| do not hold): never reuse
+            const double ib = K.generic_p0 ? __builtin_nan("") : rcp_nr(O2 - 1.0);
+            pc.Phi = Phi; pc.O2 = O2; pc.nib = nsel * ib;
+            // |x| = |d| invPhi, |y| = |d| invom, |10 d(1/Phi)| <= 12 |d| invPhi^2, |z| <= 2.2 |d| invPhi invden
+            pc.cPhi = fmax(fmax(fabs(invPhi), fabs(invom)), fmax(12.0 * (invPhi * invPhi), 2.2 * fabs(invPhi * invden)));
+            pc.set(PC_INVPHI, invPhi); pc.set(PC_INVOM, invom); pc.set(PC_INVDEN, invden); pc.set(PC_E, ex);
+            pc.set(PC_IB, ib); pc.set(PC_TC, tC);
+            live = true;
+        }
+    }
+    {   // aragonite term: always evaluated in full - it vanishes outside the dissolution zone while undersaturated
+        // (whole waves skip the power), and caching it as well costs more registers / LDS reads than it saves
+        const double O3 = O2 * K.KRat;
+        const bool under = O3 < 1.0;
+        const double msel = under ? K.m2 : K.m1;
+        tA = O3 - O3;                               // 0, or NaN for a non-finite O3 (keeps the reference's NaN visible)
+        if (!under || in_mask) {
+            const double pwA = pow_sat(fabs(O3 - 1.0), msel, T);
+            tA = (under ? 1.0 : -K.nu1) * pwA;      // (1-O3)^m2 * mask  |  -nu1 (O3-1)^m1
+        }
+        if (K.generic_p0) {
+            asm volatile("");  // a real branch, as above
+            const double z1 = C->p0_m1, z2 = C->p0_m2;
+            const double mask = in_mask ? 1.0 : 0.0;
+            const double pa = (O3 == 1.0) ? (under ? z2 : z1) : ((!under || in_mask) ? fast_exp(msel * fast_log(fabs(O3 - 1.0), T), T) : 0.0);
+            tA = under ? pa * mask - K.nu1 * z1 : z2 * mask - K.nu1 * pa;
         }
     }
     const double F = 1.0 - ex;
@@ -307,46 +369,57 @@ __device__ __forceinline__ void rhs_point(const double (&uc)[NF], const double (
     aux.U = U;
     aux.W = W;
 
-    // ---- reaction terms (:479-493).  Of each clamp pair (min(x,1), max(x,1)) one power has base exactly 0
-    // and the other has base |x - 1|; with positive exponents the zero-base member vanishes.
-    double tA = O3 - O3;                        // 0, or NaN for a non-finite O3 (keeps the reference's NaN visible)
-    if (!under || in_mask) {
-        const double pwA = pow_sat(fabs(O3 - 1.0), under ? K.m2 : K.m1, T);
-        tA = (under ? 1.0 : -K.nu1) * pwA;      // (1-O3)^m2 * mask  |  -nu1 (O3-1)^m1
-    }
-    if (K.generic_p0) {
-        const double z1 = C->p0_m1, z2 = C->p0_m2;
-        const double mask = in_mask ? 1.0 : 0.0;
-        const double pa = (O3 == 1.0) ? (under ? z2 : z1) : ((!under || in_mask) ? fast_exp((under ? K.m2 : K.m1) * fast_log(fabs(O3 - 1.0), T), T) : 0.0);
-        tA = under ? pa * mask - K.nu1 * z1 : z2 * mask - K.nu1 * pa;
-    }
+    // ---- reaction terms (:479-493)
     const double DA = K.Da * (CA * tA);          // Da coA
     const double DC = K.Dal * (CC * tC);         // Da lambda coC
     const double DmD = DA - DC;
     const double DaR = omPhi * DmD;              // Da (1-Phi) (coA - lambda coC)
+    // solids (:498-503): (1-CA) DA + CA DC = DA - CA (DA - DC);  CC DA + (1-CC) DC = DC + CC (DA - DC)
+    pl.upw = U > 0.0;
+    pl.Ux = fabs(U * K.inv_dx);
+    pl.R0 = __builtin_fma(CA, DmD, -DA);
+    pl.R1 = __builtin_fma(CC, DmD, DC);
 
-    // ---- solids: upwinded one-sided difference (:372-384, :418-423) and rates (:498-503).
-    //   U > 0: -U (u - u[i-1])/dx;  else: -U (u[i+1] - u)/dx = -|U| (u - u[i+1])/dx   -> one difference against
-    //   the upwind neighbour;  (1-CA) DA + CA DC = DA - CA (DA - DC);  CC DA + (1-CC) DC = DC + CC (DA - DC).
-    const bool upw = U > 0.0;
-    const double Ux = fabs(U * K.inv_dx);
-    r[0] = __builtin_fma(-Ux, CA - (upw ? um[0] : up[0]), __builtin_fma(CA, DmD, -DA));
-    r[1] = __builtin_fma(-Ux, CC - (upw ? um[1] : up[1]), __builtin_fma(CC, DmD, DC));
-
-    // ---- solutes and porosity.  Fiadeiro-Veronis weights (:433-462) all vanish when every |Pe| < PECLET_MIN
-    // (always on fine grids): then the weighted gradient 0.5*((1-s) forw + (1+s) back) is the central one.
+    // ---- Fiadeiro-Veronis weights (:433-462) all vanish when every |Pe| < PECLET_MIN (always on fine grids)
     const double Wd = W * den;
     bool fv_active = false;
     if (fv_check) {
         const double pmax = fmax(fabs(Wd) * K.pe_smax, fabs(W) * K.pe_Phi);
         fv_active = !(pmax < PECLET_MIN);
-        if constexpr (MODE == TR_FILL) pc.fv_quiet = pmax < 0.9 * PECLET_MIN;  // later stages move Pe by < 1e-3 relative
-    } else if constexpr (MODE == TR_FILL) {
-        pc.fv_quiet = true;  // FV_switch off
+        if constexpr (MODE == TR_FILL || MODE == TR_AUTO) { if (!reuse) pc.fv_quiet = pmax < 0.9 * PECLET_MIN; }  // in range, Pe moves by < 1e-3 relative
+    } else if constexpr (MODE == TR_FILL || MODE == TR_AUTO) {
+        if (!reuse) pc.fv_quiet = true;  // FV_switch off
     }
-    const double h1x = (Phi * invden) * K.inv_dx2;                  // Phi/den / dx^2
-    const double h2f = invden * __builtin_fma(2.0, invden, 1.0);    // (2+den)/den^2
+    pl.fv_active = fv_active;
+    pl.Wd = Wd;
+    pl.W = W;
+    pl.invPhi = invPhi;
+    const double DaRi = DaR * invPhi;
+    pl.G2 = DaRi * (K.delta - c);                                   // :506-509, :512-515
+    pl.G3 = DaRi * (K.delta - o);
+    pl.h1x = (Phi * invden) * K.inv_dx2;                            // Phi/den / dx^2
+    pl.h2f = invden * __builtin_fma(2.0, invden, 1.0);              // (2+den)/den^2
     const double q = __builtin_fma(rF, __builtin_fma(2.0, Phi, 10.0), -K.rr10);  // rhorat (2 Phi F + 10 (F-1))  (:495)
+    pl.Q4 = __builtin_fma(-Phi, q, W);                              // -(dWdx Phi + W Phi') = -Phi' (W - Phi q)  (:518-520)
+    pl.DaR = DaR;
+}
+#pragma clang diagnostic pop
+
+// uc/um/up: values at cell i, i-1, i+1 (ghosts already substituted).  r: the five rates (LHeureux_model.py:498-520).
+__device__ __forceinline__ void point_rates(const double (&uc)[NF], const double (&um)[NF], const double (&up)[NF],
+                                            const HotConsts& K, const Tables& T, const PointLocal& pl, double (&r)[NF])
+{
+#ifdef MARL_ABLATE_CORE
+    for (int f = 0; f < NF; f++) r[f] = (up[f] - um[f]) * K.hdx * 1e-9;
+    return;
+#endif
+    const double CA = uc[0], CC = uc[1], c = uc[2], o = uc[3], Phi = uc[4];
+    // ---- solids: upwinded one-sided difference (:372-384, :418-423).
+    //   U > 0: -U (u - u[i-1])/dx;  else: -U (u[i+1] - u)/dx = -|U| (u - u[i+1])/dx  -> one difference, upwind neighbour
+    r[0] = __builtin_fma(-pl.Ux, CA - (pl.upw ? um[0] : up[0]), pl.R0);
+    r[1] = __builtin_fma(-pl.Ux, CC - (pl.upw ? um[1] : up[1]), pl.R1);
+
+    // ---- solutes and porosity.
     // one-sided differences (x dx): back = u - u[i-1], forw = u[i+1] - u (:372-384) - both exact for smooth fields
     // (Sterbenz), so forw - back is a second difference WITHOUT the 1-ulp-of-u noise of u[i-1] - 2u + u[i+1]
     // (which, times 1/dx^2, is what limits the reference's own RHS to ~1e-10 relative on fine grids).
@@ -355,24 +428,35 @@ __device__ __forceinline__ void rhs_point(const double (&uc)[NF], const double (
     const double p_b = Phi - um[4], p_f = up[4] - Phi;
     const double p_d = p_f - p_b, c_d = c_f - c_b, o_d = o_f - o_b;
     double pg, cg, og;  // gradients (already divided by dx)
-    if (!fv_active) {
+    if (!pl.fv_active) {   // weighted gradient 0.5*((1-s) forw + (1+s) back) with s = 0: the central one
         pg = (p_f + p_b) * K.hdx;
         cg = (c_f + c_b) * K.hdx;
         og = (o_f + o_b) * K.hdx;
     } else {
+        const double W = pl.W, Wd = pl.Wd;
         const double s_c = fv_sigma(Wd * K.pe_cCa, W, T), s_o = fv_sigma(Wd * K.pe_cCO3, W, T), s_p = fv_sigma(W * K.pe_Phi, W, T);
         cg = ((1.0 - s_c) * c_f + (1.0 + s_c) * c_b) * K.hdx;
         og = ((1.0 - s_o) * o_f + (1.0 + s_o) * o_b) * K.hdx;
         pg = ((1.0 - s_p) * p_f + (1.0 + s_p) * p_b) * K.hdx;
     }
-    const double h2 = pg * h2f;                                      // common_helper2 (:472-473)
-    const double Hc = K.dCa * __builtin_fma(h2, cg, h1x * c_d);      // (:474-475)
-    const double Ho = K.dCO3 * __builtin_fma(h2, og, h1x * o_d);     // (:476-477)
-    r[2] = __builtin_fma(-W, cg, __builtin_fma(DaR, K.delta - c, Hc) * invPhi);   // :506-509
-    r[3] = __builtin_fma(-W, og, __builtin_fma(DaR, K.delta - o, Ho) * invPhi);   // :512-515
-    // -(dWdx Phi + W Phi') with dWdx = -q Phi'  ->  -Phi' (W - Phi q)             // :495, :518-520
-    r[4] = __builtin_fma(-pg, __builtin_fma(-Phi, q, W), __builtin_fma(K.dPhi_dx2, p_d, DaR));
+    const double h2 = pg * pl.h2f;                                      // common_helper2 (:472-473)
+    const double Hc = K.dCa * __builtin_fma(h2, cg, pl.h1x * c_d);      // (:474-475)
+    const double Ho = K.dCO3 * __builtin_fma(h2, og, pl.h1x * o_d);     // (:476-477)
+    r[2] = __builtin_fma(-pl.W, cg, __builtin_fma(pl.invPhi, Hc, pl.G2));   // :506-509
+    r[3] = __builtin_fma(-pl.W, og, __builtin_fma(pl.invPhi, Ho, pl.G3));   // :512-515
+    r[4] = __builtin_fma(-pg, pl.Q4, __builtin_fma(K.dPhi_dx2, p_d, pl.DaR));  // :518-520
 }
-#pragma clang diagnostic pop
+
+// Both phases back to back (stand-alone RHS).
+template <int MODE, int STRIDE>
+__device__ __forceinline__ void rhs_point(const double (&uc)[NF], const double (&um)[NF], const double (&up)[NF],
+                                          bool in_mask, const HotConsts& K, const DevConsts* __restrict__ C,
+                                          const Tables& T, double (&r)[NF], PointAux& aux, PointCache<STRIDE>& pc, bool& live)
+{
+    PointLocal pl;
+    point_local<MODE>(uc, in_mask, K, C, T, pl, aux, pc, live);
+    point_rates(uc, um, up, K, T, pl, r);
+}
+
 
 }  // namespace marl
