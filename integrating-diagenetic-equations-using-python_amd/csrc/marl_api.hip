@@ -466,7 +466,7 @@ static int launch_attempt(marl_ctx* ctx, int v, int layout)
         default: return fail(ctx, -1, "rk45 variant %d not instantiated", v);
     }
     LAUNCH_OK(ctx);
-    hipLaunchKernelGGL(rk45_control_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->part, nb, ctx->dctrl);
+    hipLaunchKernelGGL(rk45_control_kernel, dim3(1), dim3(CONTROL_THREADS), 0, ctx->stream, ctx->part, nb, ctx->dctrl);
     LAUNCH_OK(ctx);
     return 0;
 }
@@ -975,7 +975,7 @@ int marl_slab_control(marl_ctx* ctx, const double* recs_dev, int64_t nrec)
 {
     SLAB_OK(ctx, "marl_slab_control")
     if (!recs_dev || nrec < 1) return fail(ctx, -1, "marl_slab_control: invalid argument");
-    hipLaunchKernelGGL(rk45_control_kernel, dim3(1), dim3(256), 0, ctx->stream, recs_dev, nrec, ctx->dctrl);
+    hipLaunchKernelGGL(rk45_control_kernel, dim3(1), dim3(CONTROL_THREADS), 0, ctx->stream, recs_dev, nrec, ctx->dctrl);
     LAUNCH_OK(ctx);
     return 0;
 }

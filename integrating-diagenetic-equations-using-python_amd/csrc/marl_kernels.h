@@ -152,39 +152,46 @@ struct StencilBlock {
     }
 };
 
-// Block-wide reduction of NQ quantities: q[0] summed, q[1..NMIN] min-reduced, the rest max-reduced.
-// Result valid in thread 0.  `scratch` holds NQ * (BLK/64) doubles.
+// Block-wide reduction of NQ quantities: q[0] summed, q[1..NMIN] min-reduced, the rest max-reduced, in a fixed
+// order (deterministic).  Result valid in thread 0.  `scratch`: NQ * BLK doubles of LDS that no thread still reads
+// for another purpose once it has arrived here (the stencil kernels pass their edge-exchange buffers).
+// The quantities are transposed through LDS so that each wave reduces whole quantities: NQ/waves butterfly
+// reductions per wave instead of NQ (a 64-lane butterfly of one double costs 12 ds_bpermute + the combines).
 template <int BLK, int NQ, int NMIN>
 __device__ __forceinline__ void block_reduce(double (&q)[NQ], double* scratch)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-        for (int j = 0; j < NQ; j++) {
-            const double o = __shfl_xor(q[j], off, 64);
-            q[j] = (j == 0) ? q[j] + o : (j <= NMIN ? nanmin(q[j], o) : nanmax(q[j], o));
-        }
-    }
     constexpr int NW = BLK / 64;
+    auto combine = [](int j, double a, double o) { return (j == 0) ? a + o : (j <= NMIN ? nanmin(a, o) : nanmax(a, o)); };
     if constexpr (NW > 1) {
-        if (lane == 0) {
+        __syncthreads();
 #pragma unroll
-            for (int j = 0; j < NQ; j++) scratch[j * NW + wave] = q[j];
+        for (int j = 0; j < NQ; j++) scratch[j * BLK + threadIdx.x] = q[j];
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < (NQ + NW - 1) / NW; jj++) {
+            const int j = wave + jj * NW;   // wave-uniform
+            if (j < NQ) {
+                double a = scratch[j * BLK + lane];
+#pragma unroll
+                for (int i = 1; i < NW; i++) a = combine(j, a, scratch[j * BLK + lane + 64 * i]);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) a = combine(j, a, __shfl_xor(a, off, 64));
+                if (lane == 0) scratch[j * BLK] = a;
+            }
         }
         __syncthreads();
         if (threadIdx.x == 0) {
 #pragma unroll
-            for (int j = 0; j < NQ; j++) {
-                double a = scratch[j * NW];
-                for (int w = 1; w < NW; w++) {
-                    const double o = scratch[j * NW + w];
-                    a = (j == 0) ? a + o : (j <= NMIN ? nanmin(a, o) : nanmax(a, o));
-                }
-                q[j] = a;
-            }
+            for (int j = 0; j < NQ; j++) q[j] = scratch[j * BLK];
         }
         __syncthreads();
+    } else {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+            for (int j = 0; j < NQ; j++) q[j] = combine(j, q[j], __shfl_xor(q[j], off, 64));
+        }
     }
 }
 
@@ -282,7 +289,7 @@ template <int LAYOUT>
 __global__ void __launch_bounds__(256) monitors_kernel(const double* __restrict__ y, const DevConsts* __restrict__ consts,
                                                        Slab S, int64_t inst_stride, double* __restrict__ part)
 {
-    __shared__ double scratch[NQ * 4];
+    __shared__ double scratch[NQ * 256];
     __shared__ double tabs[TABLE_DOUBLES];
     const Tables T = load_tables(tabs, 256);
     const DevConsts& C = consts[blockIdx.y];
@@ -309,7 +316,7 @@ __global__ void __launch_bounds__(256) monitors_kernel(const double* __restrict_
 // Deterministic second-level reduction: `nblocks` records -> one record per instance.
 __global__ void __launch_bounds__(256) reduce_records_kernel(const double* __restrict__ part, int64_t nblocks, double* __restrict__ out)
 {
-    __shared__ double scratch[NQ * 4];
+    __shared__ double scratch[NQ * 256];
     part += (int64_t)blockIdx.x * nblocks * NQ;
     double q[NQ];
     monitors_init(q);
@@ -561,24 +568,41 @@ __global__ void rk45_resume_kernel(Rk45Ctrl* ctrl, double pause_t, int64_t max_a
 
 // Combine `nrec` reduction records (per-block partials on one GPU, or one record per rank after the
 // all-gather of a domain-decomposed run) in index order and finish the attempt.
-__global__ void __launch_bounds__(256) rk45_control_kernel(const double* __restrict__ recs, int64_t nrec, Rk45Ctrl* ctrl)
+// One workgroup of 512 threads: with thousands of block records the reduction is latency-bound, so it is spread
+// over many lanes (4 300 records at N = 2^20: ~8 per thread).
+constexpr int CONTROL_THREADS = 512;
+__global__ void __launch_bounds__(CONTROL_THREADS) rk45_control_kernel(const double* __restrict__ recs, int64_t nrec, Rk45Ctrl* ctrl)
 {
-    __shared__ double scratch[NQ * 4];
-    if (ctrl->status != ST_RUNNING) return;
+    __shared__ double scratch[NQ * CONTROL_THREADS];
+#ifdef MARL_CTL_CLOCK
+    const unsigned long long c0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int32_t status = ctrl->status;
     double q[NQ];
     monitors_init(q);
-    for (int64_t b = threadIdx.x; b < nrec; b += 256) {
+    for (int64_t b = threadIdx.x; b < nrec; b += CONTROL_THREADS) {
+        double o[NQ];
 #pragma unroll
-        for (int j = 0; j < NQ; j++) {
-            const double o = recs[b * NQ + j];
-            q[j] = (j == 0) ? q[j] + o : (j <= NQMIN ? nanmin(q[j], o) : nanmax(q[j], o));
-        }
+        for (int j = 0; j < NQ; j++) o[j] = recs[b * NQ + j];
+#pragma unroll
+        for (int j = 0; j < NQ; j++) q[j] = (j == 0) ? q[j] + o[j] : (j <= NQMIN ? nanmin(q[j], o[j]) : nanmax(q[j], o[j]));
     }
-    block_reduce<256, NQ, NQMIN>(q, scratch);
+    if (status != ST_RUNNING) return;   // (read first, tested last: the record loads do not wait for it)
+#ifdef MARL_CTL_CLOCK
+    const unsigned long long c1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    block_reduce<CONTROL_THREADS, NQ, NQMIN>(q, scratch);
+#ifdef MARL_CTL_CLOCK
+    const unsigned long long c2 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (threadIdx.x == 0) {
         Rk45Ctrl c = *ctrl;
         rk45_finish_attempt(c, q);
         *ctrl = c;
+#ifdef MARL_CTL_CLOCK
+        const unsigned long long c3 = __builtin_amdgcn_s_memrealtime();
+        if (c.attempts == 300) printf("CTLCLOCK load %llu reduce %llu finish %llu (x10 ns)\n", c1 - c0, c2 - c1, c3 - c2);
+#endif
     }
 }
 
@@ -640,7 +664,7 @@ __global__ void __launch_bounds__(BLK) rk45_attempt_kernel(double* __restrict__ 
     constexpr int H = 6;
     constexpr int WIN = BLK * CPT;
     constexpr int V = WIN - 2 * H;
-    __shared__ double lds[StencilBlock<BLK, CPT>::LDS_DOUBLES + NQ * (BLK / 64)];
+    __shared__ double lds[StencilBlock<BLK, CPT>::LDS_DOUBLES];
     if (ctrl->status != ST_RUNNING) return;
     const DevConsts& C = consts[0];
     const int cur = ctrl->cur;
@@ -652,11 +676,10 @@ __global__ void __launch_bounds__(BLK) rk45_attempt_kernel(double* __restrict__ 
 
     const int64_t w0 = S.out_lo + (int64_t)blockIdx.x * V - H;
     const int64_t l0 = w0 + (int64_t)threadIdx.x * CPT;
-    StencilBlock<BLK, CPT> sb(lds, l0 + S.goff, consts);
 
     double y[CPT][NF], k1[CPT][NF], yn[CPT][NF], k7[CPT][NF], esum[CPT][NF];
     PointAux aux[CPT];
-    load_cells<CPT, LAYOUT>(yin, l0, S, C, y);
+    load_cells<CPT, LAYOUT>(yin, l0, S, C, y);              // in flight while the tables are staged
 #pragma unroll
     for (int c = 0; c < CPT; c++) {
         const int64_t l = l0 + c;
@@ -664,6 +687,7 @@ __global__ void __launch_bounds__(BLK) rk45_attempt_kernel(double* __restrict__ 
 #pragma unroll
         for (int f = 0; f < NF; f++) k1[c][f] = in ? fin[at<LAYOUT>(f, l, S.ld)] : 0.0;
     }
+    StencilBlock<BLK, CPT> sb(lds, l0 + S.goff, consts);   // (table copy + barrier inside)
     dp45_attempt<BLK, CPT>(sb, h, y, k1, yn, k7, esum, aux);
 
     double q[NQ];
@@ -682,7 +706,7 @@ __global__ void __launch_bounds__(BLK) rk45_attempt_kernel(double* __restrict__ 
             monitors_accumulate(q, yn[c], aux[c].U, aux[c].W);
         }
     }
-    block_reduce<BLK, NQ, NQMIN>(q, lds + StencilBlock<BLK, CPT>::LDS_DOUBLES);
+    block_reduce<BLK, NQ, NQMIN>(q, lds);   // the edge-exchange buffers are free now
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int j = 0; j < NQ; j++) part[(int64_t)blockIdx.x * NQ + j] = q[j];
@@ -709,7 +733,7 @@ __global__ void __launch_bounds__(BLK) rk45_dense_kernel(const double* __restric
     constexpr int H = 6;
     constexpr int WIN = BLK * CPT;
     constexpr int V = WIN - 2 * H;
-    __shared__ double lds[StencilBlock<BLK, CPT>::LDS_DOUBLES + NQ * (BLK / 64)];
+    __shared__ double lds[StencilBlock<BLK, CPT>::LDS_DOUBLES];
     const DevConsts& C = consts[0];
     const int64_t w0 = S.out_lo + (int64_t)blockIdx.x * V - H;
     const int64_t l0 = w0 + (int64_t)threadIdx.x * CPT;
@@ -743,7 +767,7 @@ __global__ void __launch_bounds__(BLK) rk45_dense_kernel(const double* __restric
             monitors_accumulate(q, d, U, W);
         }
     }
-    block_reduce<BLK, NQ, NQMIN>(q, lds + StencilBlock<BLK, CPT>::LDS_DOUBLES);
+    block_reduce<BLK, NQ, NQMIN>(q, lds);   // the edge-exchange buffers are free now
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int j = 0; j < NQ; j++) part[(int64_t)blockIdx.x * NQ + j] = q[j];
@@ -823,7 +847,7 @@ __global__ void __launch_bounds__(BLK) rk45_sweep_kernel(double* __restrict__ Y,
                                                          double* __restrict__ Yold, double* __restrict__ Fold)
 {
     using SB = StencilBlock<BLK, CPT, false>;
-    __shared__ double lds[SB::LDS_DOUBLES + NQ * (BLK / 64)];
+    __shared__ double lds[SB::LDS_DOUBLES];
     __shared__ Rk45Ctrl sc;
     const DevConsts& C = consts[blockIdx.x];
     double* yg = Y + (int64_t)blockIdx.x * NF * N;
@@ -853,7 +877,7 @@ __global__ void __launch_bounds__(BLK) rk45_sweep_kernel(double* __restrict__ Y,
                 monitors_accumulate(q, yn[c], aux[c].U, aux[c].W);
             }
         }
-        block_reduce<BLK, NQ, NQMIN>(q, lds + SB::LDS_DOUBLES);
+        block_reduce<BLK, NQ, NQMIN>(q, lds);   // the edge-exchange buffers are free now
         if (threadIdx.x == 0) rk45_finish_attempt(sc, q);
         __syncthreads();
         const int status = sc.status;
