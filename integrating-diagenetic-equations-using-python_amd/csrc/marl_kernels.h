@@ -620,7 +620,10 @@ __device__ __forceinline__ void dp45_attempt(SB& sb, double h,
 {
     const double e1 = DENSE ? dw.w[0] : dp::E1, e3 = DENSE ? dw.w[2] : dp::E3, e4 = DENSE ? dw.w[3] : dp::E4;
     const double e5 = DENSE ? dw.w[4] : dp::E5, e6 = DENSE ? dw.w[5] : dp::E6, e7 = DENSE ? dw.w[6] : dp::E7;
-    double ys[CPT][NF], k2[CPT][NF], k3[CPT][NF], k4[CPT][NF], k5[CPT][NF], k6[CPT][NF];
+    // K1..K4 are folded into the partial sums of everything that still needs them as soon as K4 exists, so that at
+    // most five vectors (instead of seven) are live across an evaluation.  The order of every
+    // sum is the left-to-right order of np.dot(K[:s].T, a[:s]) (rk.py:61-69).
+    double ys[CPT][NF], k2[CPT][NF], k3[CPT][NF], k4[CPT][NF], kk[CPT][NF], s6[CPT][NF], bn[CPT][NF];
 #define MARL_CELLS _Pragma("unroll") for (int c = 0; c < CPT; c++) _Pragma("unroll") for (int f = 0; f < NF; f++)
     MARL_CELLS ys[c][f] = y[c][f] + (k1[c][f] * dp::A21) * h;
     sb.template eval<TR_FILL>(ys, k2, aux);
@@ -628,13 +631,22 @@ __device__ __forceinline__ void dp45_attempt(SB& sb, double h,
     sb.template eval<TR_REUSE>(ys, k3, aux);
     MARL_CELLS ys[c][f] = y[c][f] + (k1[c][f] * dp::A41 + k2[c][f] * dp::A42 + k3[c][f] * dp::A43) * h;
     sb.template eval<TR_REUSE>(ys, k4, aux);
-    MARL_CELLS ys[c][f] = y[c][f] + (k1[c][f] * dp::A51 + k2[c][f] * dp::A52 + k3[c][f] * dp::A53 + k4[c][f] * dp::A54) * h;
-    sb.template eval<TR_REUSE>(ys, k5, aux);
-    MARL_CELLS ys[c][f] = y[c][f] + (k1[c][f] * dp::A61 + k2[c][f] * dp::A62 + k3[c][f] * dp::A63 + k4[c][f] * dp::A64 + k5[c][f] * dp::A65) * h;
-    sb.template eval<TR_REUSE>(ys, k6, aux);
     MARL_CELLS {
-        yn[c][f] = y[c][f] + h * (k1[c][f] * dp::B1 + k3[c][f] * dp::B3 + k4[c][f] * dp::B4 + k5[c][f] * dp::B5 + k6[c][f] * dp::B6);
-        esum[c][f] = k1[c][f] * e1 + k3[c][f] * e3 + k4[c][f] * e4 + k5[c][f] * e5 + k6[c][f] * e6;
+        ys[c][f] = y[c][f] + (k1[c][f] * dp::A51 + k2[c][f] * dp::A52 + k3[c][f] * dp::A53 + k4[c][f] * dp::A54) * h;
+        s6[c][f] = k1[c][f] * dp::A61 + k2[c][f] * dp::A62 + k3[c][f] * dp::A63 + k4[c][f] * dp::A64;
+        bn[c][f] = k1[c][f] * dp::B1 + k3[c][f] * dp::B3 + k4[c][f] * dp::B4;
+        esum[c][f] = k1[c][f] * e1 + k3[c][f] * e3 + k4[c][f] * e4;
+    }
+    sb.template eval<TR_REUSE>(ys, kk, aux);   // K5
+    MARL_CELLS {
+        ys[c][f] = y[c][f] + (s6[c][f] + kk[c][f] * dp::A65) * h;
+        bn[c][f] = bn[c][f] + kk[c][f] * dp::B5;
+        esum[c][f] = esum[c][f] + kk[c][f] * e5;
+    }
+    sb.template eval<TR_REUSE>(ys, kk, aux);   // K6
+    MARL_CELLS {
+        yn[c][f] = y[c][f] + h * (bn[c][f] + kk[c][f] * dp::B6);
+        esum[c][f] = esum[c][f] + kk[c][f] * e6;
     }
     sb.template eval<TR_REUSE>(yn, k7, aux);
     MARL_CELLS esum[c][f] = esum[c][f] + k7[c][f] * e7;
