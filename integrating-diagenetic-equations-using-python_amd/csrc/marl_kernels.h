@@ -123,10 +123,12 @@ struct StencilBlock {
         const int tr = tid < BLK - 1 ? tid + 1 : BLK - 1;
         double left[NF], right[NF];
 #pragma unroll
-        for (int f = 0; f < NF; f++) {
-            left[f] = e[((NSIDE - 1) * NF + f) * BLK + tl];  // left neighbour's LAST cell
-            right[f] = e[f * BLK + tr];                      // right neighbour's FIRST cell
-        }
+        for (int f = 0; f < NF; f++) left[f] = e[((NSIDE - 1) * NF + f) * BLK + tl];  // left neighbour's LAST cell
+        // the solids are differenced against the upwind neighbour only: with U > 0 in every lane (burial - the normal
+        // case) the right-hand values of CA and CC are never used and their two LDS reads are skipped
+        const bool need_right_solids = __builtin_amdgcn_ballot_w64(!pl[CPT - 1].upw) != 0;
+#pragma unroll
+        for (int f = 0; f < NF; f++) right[f] = (f >= 2 || need_right_solids) ? e[f * BLK + tr] : 0.0;  // right neighbour's FIRST cell
         parity ^= 1;
 #pragma unroll
         for (int c = 0; c < CPT; c++) {
