@@ -35,7 +35,10 @@ typedef struct marl_params {
     double shallow_limit, deep_limit;
     /* 1 = Fiadeiro-Veronis weighting of the solute/porosity gradients, 0 = central (LHeureux_model.py:433-462) */
     int32_t FV_switch;
-    int32_t reserved;
+    /* 0 = the reference's fixed porosity diffusion coefficient dPhi_fixed (LHeureux_model.py:124-133, :431);
+     * 1 = the time-varying coefficient dPhi = auxcon F Phi^3 / (1 - Phi) of the lines the reference keeps commented
+     *     out (LHeureux_model.py:222-223, :430): enters the porosity Peclet number (:452) and dPhi * Phi_laplace (:519) */
+    int32_t dPhi_variable;
 } marl_params;
 
 #define MARL_NFIELDS 5 /* CA, CC, cCa, cCO3, Phi - in this order (Evolve_scenario.py:76-86) */

@@ -81,10 +81,12 @@ class LMAHeureuxPorosityDiff:
     def __init__(self, Depths, slices_all_fields=None, not_too_shallow=None, not_too_deep=None, *,
                  CA0, CC0, cCa0, cCO30, Phi0, sedimentationrate, Xstar, Tstar, k1, k2, k3, k4, m1, m2, n1, n2,
                  b, beta, rhos, rhow, rhos0, KA, KC, muA, D0Ca, PhiNR, PhiInfty, PhiIni, DCa, DCO3, FV_switch,
-                 ShallowLimit=50.0, DeepLimit=150.0, device=0, _extra_instances=()):
+                 ShallowLimit=50.0, DeepLimit=150.0, dPhi_variable=False, device=0, _extra_instances=()):
         """Same keywords as the reference constructor.  ``not_too_shallow`` / ``not_too_deep`` (py-pde mask
         fields in the reference) are replaced by the two numbers that define them, ``ShallowLimit`` and
-        ``DeepLimit`` in cm (Evolve_scenario.py:51-54); ``slices_all_fields`` is implied by N."""
+        ``DeepLimit`` in cm (Evolve_scenario.py:51-54); ``slices_all_fields`` is implied by N.
+        ``dPhi_variable=True`` switches from the reference's fixed porosity diffusion coefficient (:124-133, :431) to
+        the time-varying one, auxcon F Phi^3/(1-Phi), that the reference keeps commented out (:222-223, :430)."""
         if not isinstance(Depths, DepthGrid):
             raise TypeError("Depths must be a DepthGrid(length=max_depth/Xstar, N=number of cells)")
         if not_too_shallow is not None or not_too_deep is not None:
@@ -97,7 +99,7 @@ class LMAHeureuxPorosityDiff:
                      Xstar=Xstar, Tstar=Tstar, k1=k1, k2=k2, k3=k3, k4=k4, m1=m1, m2=m2, n1=n1, n2=n2, b=b,
                      beta=beta, rhos=rhos, rhow=rhow, rhos0=rhos0, KA=KA, KC=KC, muA=muA, D0Ca=D0Ca,
                      PhiNR=PhiNR, PhiInfty=PhiInfty, PhiIni=PhiIni, DCa=DCa, DCO3=DCO3, FV_switch=FV_switch,
-                     ShallowLimit=ShallowLimit, DeepLimit=DeepLimit)
+                     ShallowLimit=ShallowLimit, DeepLimit=DeepLimit, dPhi_variable=bool(dPhi_variable))
         self.instances = [first, *_extra_instances]
         for k, v in first.items():   # the reference exposes its parameters as attributes
             setattr(self, k, v)
@@ -113,6 +115,7 @@ class LMAHeureuxPorosityDiff:
             blk.shallow_limit = float(inst["ShallowLimit"]) / float(inst["Xstar"])
             blk.deep_limit = float(inst["DeepLimit"]) / float(inst["Xstar"])
             blk.FV_switch = int(inst["FV_switch"])
+            blk.dPhi_variable = int(bool(inst.get("dPhi_variable", False)))
         rc = self._lib.marl_ctx_create(blocks, len(self.instances), N, self.device, C.byref(self._ctx))
         if rc != 0:
             self._ctx = C.c_void_p()

@@ -26,7 +26,7 @@ PARAM_DOUBLES = (
 
 
 class MarlParams(C.Structure):
-    _fields_ = [(n, C.c_double) for n in PARAM_DOUBLES] + [("FV_switch", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [(n, C.c_double) for n in PARAM_DOUBLES] + [("FV_switch", C.c_int32), ("dPhi_variable", C.c_int32)]
 
 
 class MarlStats(C.Structure):

@@ -24,6 +24,7 @@ struct marl_ctx {
     int64_t N = 0, batch = 0;
     Slab slab{};
     int halo = 0;  // > 0: a slab context of a domain-decomposed grid
+    bool var_dphi = false;  // marl_params.dPhi_variable (the same for every instance): selects the VD kernel instantiations
     std::vector<marl_params> params;
     std::vector<DevConsts> hconsts;
     std::vector<double> extra;  // per instance: delta_x, auxcon, rhorat0, F_fixed (not needed on device)
@@ -108,6 +109,8 @@ static void derive_consts(const marl_params& p, int64_t N, DevConsts& c, double 
     k.Dal = k.Da * k.lambda_;
     k.rr10 = 10.0 * k.rhorat;
     k.dPhi_dx2 = k.dPhi * k.inv_dx2;
+    k.auxcon = auxcon;
+    k.var_dphi = p.dPhi_variable ? 1 : 0;
     const double bc[NF] = {p.CA0, p.CC0, p.cCa0, p.cCO30, p.Phi0};
     for (int f = 0; f < NF; f++) c.bc[f] = bc[f];
     c.N = N;
@@ -175,8 +178,13 @@ int marl_ctx_create(const marl_params* params, int64_t n_instances, int64_t N, i
     for (int64_t b = 0; b < n_instances; b++) {
         const marl_params& p = params[b];
         if (!(p.length > 0)) { delete ctx; return fail(nullptr, -1, "marl_ctx_create: instance %lld: length must be > 0", (long long)b); }
+        if ((p.dPhi_variable != 0) != (params[0].dPhi_variable != 0)) {
+            delete ctx;
+            return fail(nullptr, -1, "marl_ctx_create: dPhi_variable must be the same for every instance of a sweep");
+        }
         derive_consts(p, N, ctx->hconsts[b], &ctx->extra[4 * b]);
     }
+    ctx->var_dphi = params[0].dPhi_variable != 0;
 #define CREATE_OK(call)                                                                     \
     do {                                                                                    \
         hipError_t e2_ = (call);                                                            \
@@ -270,10 +278,16 @@ static inline int64_t inst_stride(const marl_ctx* ctx, int layout) { return stat
 static int launch_rhs(marl_ctx* ctx, const double* y, double* dydt, int layout)
 {
     const dim3 grid((unsigned)((ctx->slab.n_buf + 255) / 256), (unsigned)ctx->batch);
-    if (layout == LAYOUT_TILED)
-        hipLaunchKernelGGL(rhs_kernel<LAYOUT_TILED>, grid, dim3(256), 0, ctx->stream, y, dydt, ctx->dconsts, ctx->slab, inst_stride(ctx, layout));
+    const int64_t stride = inst_stride(ctx, layout);
+    if (ctx->var_dphi) {
+        if (layout == LAYOUT_TILED)
+            hipLaunchKernelGGL((rhs_kernel<LAYOUT_TILED, true>), grid, dim3(256), 0, ctx->stream, y, dydt, ctx->dconsts, ctx->slab, stride);
+        else
+            hipLaunchKernelGGL((rhs_kernel<LAYOUT_FIELD_MAJOR, true>), grid, dim3(256), 0, ctx->stream, y, dydt, ctx->dconsts, ctx->slab, stride);
+    } else if (layout == LAYOUT_TILED)
+        hipLaunchKernelGGL(rhs_kernel<LAYOUT_TILED>, grid, dim3(256), 0, ctx->stream, y, dydt, ctx->dconsts, ctx->slab, stride);
     else
-        hipLaunchKernelGGL(rhs_kernel<LAYOUT_FIELD_MAJOR>, grid, dim3(256), 0, ctx->stream, y, dydt, ctx->dconsts, ctx->slab, inst_stride(ctx, layout));
+        hipLaunchKernelGGL(rhs_kernel<LAYOUT_FIELD_MAJOR>, grid, dim3(256), 0, ctx->stream, y, dydt, ctx->dconsts, ctx->slab, stride);
     LAUNCH_OK(ctx);
     return 0;
 }
@@ -327,26 +341,31 @@ static const Rk4Variant kRk4Variants[] = {
 };
 constexpr int kNumRk4Variants = sizeof(kRk4Variants) / sizeof(kRk4Variants[0]);
 
-template <int BLK, int CPT, int NSTEPS>
+template <int BLK, int CPT, int NSTEPS, bool VD = false>
 static void launch_rk4_t(marl_ctx* ctx, const double* yin, double* yout, int layout, double dt)
 {
     constexpr int V = BLK * CPT - 8 * NSTEPS;
     const int64_t n = ctx->slab.out_hi - ctx->slab.out_lo;
     const dim3 grid((unsigned)((n + V - 1) / V));
     if (layout == LAYOUT_TILED)
-        hipLaunchKernelGGL((rk4_fused_kernel<BLK, CPT, LAYOUT_TILED, NSTEPS>), grid, dim3(BLK), 0, ctx->stream, yin, yout, ctx->dconsts, ctx->slab, dt);
+        hipLaunchKernelGGL((rk4_fused_kernel<BLK, CPT, LAYOUT_TILED, NSTEPS, VD>), grid, dim3(BLK), 0, ctx->stream, yin, yout, ctx->dconsts, ctx->slab, dt);
     else
-        hipLaunchKernelGGL((rk4_fused_kernel<BLK, CPT, LAYOUT_FIELD_MAJOR, NSTEPS>), grid, dim3(BLK), 0, ctx->stream, yin, yout, ctx->dconsts, ctx->slab, dt);
+        hipLaunchKernelGGL((rk4_fused_kernel<BLK, CPT, LAYOUT_FIELD_MAJOR, NSTEPS, VD>), grid, dim3(BLK), 0, ctx->stream, yin, yout, ctx->dconsts, ctx->slab, dt);
 }
+
+// The kernel sets instantiated with the time-varying porosity diffusion coefficient (dPhi_variable): one
+// one-cell-per-thread shape per integrator - the option is a model variant, not a tuning surface.
+constexpr int kVdRk4Variant = 10;   // {256, 1, 4}
+constexpr int kVdRk45Variant = 0;   // {256, 1}
 
 static int launch_rk4(marl_ctx* ctx, int v, bool single, const double* yin, double* yout, int layout, double dt)
 {
     const Rk4Variant& rv = kRk4Variants[v];
     const int key = rv.blk * 1000 + rv.cpt * 100 + (single ? 1 : rv.nsteps);
     switch (key) {
-        case 256101: launch_rk4_t<256, 1, 1>(ctx, yin, yout, layout, dt); break;
+        case 256101: if (ctx->var_dphi) launch_rk4_t<256, 1, 1, true>(ctx, yin, yout, layout, dt); else launch_rk4_t<256, 1, 1>(ctx, yin, yout, layout, dt); break;
         case 256102: launch_rk4_t<256, 1, 2>(ctx, yin, yout, layout, dt); break;
-        case 256104: launch_rk4_t<256, 1, 4>(ctx, yin, yout, layout, dt); break;
+        case 256104: if (ctx->var_dphi) launch_rk4_t<256, 1, 4, true>(ctx, yin, yout, layout, dt); else launch_rk4_t<256, 1, 4>(ctx, yin, yout, layout, dt); break;
         case 256108: launch_rk4_t<256, 1, 8>(ctx, yin, yout, layout, dt); break;
         case 256201: launch_rk4_t<256, 2, 1>(ctx, yin, yout, layout, dt); break;
         case 256202: launch_rk4_t<256, 2, 2>(ctx, yin, yout, layout, dt); break;
@@ -364,6 +383,7 @@ static int launch_rk4(marl_ctx* ctx, int v, bool single, const double* yin, doub
 
 static int default_rk4_variant(const marl_ctx* ctx)
 {
+    if (ctx->var_dphi) return kVdRk4Variant;
     if (ctx->rk4_variant >= 0 && ctx->rk4_variant < kNumRk4Variants) return (int)ctx->rk4_variant;
     const int64_t n = ctx->slab.out_hi - ctx->slab.out_lo;
     return n <= 131072 ? 5 : 10;  // small grids: 8 steps/launch on 128-thread blocks (launch bound); large: 4 steps/launch
@@ -398,7 +418,7 @@ constexpr int kNumSweepVariants = sizeof(kSweepVariants) / sizeof(kSweepVariants
 
 static int default_sweep_variant(marl_ctx* ctx)
 {
-    if (ctx->sweep_variant >= 0 && ctx->sweep_variant < kNumSweepVariants) {
+    if (!ctx->var_dphi && ctx->sweep_variant >= 0 && ctx->sweep_variant < kNumSweepVariants) {
         const SweepVariant& sv = kSweepVariants[ctx->sweep_variant];
         if ((int64_t)sv.blk * sv.cpt >= ctx->N) return (int)ctx->sweep_variant;
     }
@@ -407,6 +427,7 @@ static int default_sweep_variant(marl_ctx* ctx)
     int64_t best_win = 0;
     for (int i : order) {
         const int64_t win = (int64_t)kSweepVariants[i].blk * kSweepVariants[i].cpt;
+        if (ctx->var_dphi && kSweepVariants[i].cpt != 1) continue;   // VD kernels: the one-cell-per-thread shapes only
         if (win >= ctx->N && (best < 0 || win < best_win)) { best = i; best_win = win; }
     }
     return best;
@@ -416,13 +437,16 @@ static int default_sweep_variant(marl_ctx* ctx)
     switch (v) {                                                                                              \
         case 0: hipLaunchKernelGGL((KERNEL<256, 4>), grid, dim3(256), 0, ctx->stream, __VA_ARGS__); break;    \
         case 1: hipLaunchKernelGGL((KERNEL<512, 2>), grid, dim3(512), 0, ctx->stream, __VA_ARGS__); break;    \
-        case 2: hipLaunchKernelGGL((KERNEL<1024, 1>), grid, dim3(1024), 0, ctx->stream, __VA_ARGS__); break;  \
-        case 3: hipLaunchKernelGGL((KERNEL<256, 1>), grid, dim3(256), 0, ctx->stream, __VA_ARGS__); break;    \
+        case 2: if (ctx->var_dphi) hipLaunchKernelGGL((KERNEL<1024, 1, true>), grid, dim3(1024), 0, ctx->stream, __VA_ARGS__); \
+                else hipLaunchKernelGGL((KERNEL<1024, 1>), grid, dim3(1024), 0, ctx->stream, __VA_ARGS__); break;  \
+        case 3: if (ctx->var_dphi) hipLaunchKernelGGL((KERNEL<256, 1, true>), grid, dim3(256), 0, ctx->stream, __VA_ARGS__); \
+                else hipLaunchKernelGGL((KERNEL<256, 1>), grid, dim3(256), 0, ctx->stream, __VA_ARGS__); break;    \
         case 4: hipLaunchKernelGGL((KERNEL<128, 2>), grid, dim3(128), 0, ctx->stream, __VA_ARGS__); break;    \
         case 5: hipLaunchKernelGGL((KERNEL<64, 4>), grid, dim3(64), 0, ctx->stream, __VA_ARGS__); break;      \
         case 6: hipLaunchKernelGGL((KERNEL<256, 2>), grid, dim3(256), 0, ctx->stream, __VA_ARGS__); break;    \
         case 7: hipLaunchKernelGGL((KERNEL<128, 4>), grid, dim3(128), 0, ctx->stream, __VA_ARGS__); break;    \
-        case 8: hipLaunchKernelGGL((KERNEL<512, 1>), grid, dim3(512), 0, ctx->stream, __VA_ARGS__); break;    \
+        case 8: if (ctx->var_dphi) hipLaunchKernelGGL((KERNEL<512, 1, true>), grid, dim3(512), 0, ctx->stream, __VA_ARGS__); \
+                else hipLaunchKernelGGL((KERNEL<512, 1>), grid, dim3(512), 0, ctx->stream, __VA_ARGS__); break;    \
         default: return fail(ctx, -1, "sweep variant %d not instantiated", v);                                \
     }
 
@@ -433,6 +457,7 @@ constexpr int kNumRk45Variants = sizeof(kRk45Variants) / sizeof(kRk45Variants[0]
 
 static int default_rk45_variant(const marl_ctx* ctx)
 {
+    if (ctx->var_dphi) return kVdRk45Variant;
     if (ctx->rk45_variant >= 0 && ctx->rk45_variant < kNumRk45Variants) return (int)ctx->rk45_variant;
     return 0;
 }
@@ -444,14 +469,14 @@ static int64_t rk45_blocks(const marl_ctx* ctx, int v)
     return (n + V - 1) / V;
 }
 
-template <int BLK, int CPT>
+template <int BLK, int CPT, bool VD = false>
 static void launch_attempt_t(marl_ctx* ctx, int64_t nb, int layout)
 {
     if (layout == LAYOUT_TILED)
-        hipLaunchKernelGGL((rk45_attempt_kernel<BLK, CPT, LAYOUT_TILED>), dim3((unsigned)nb), dim3(BLK), 0, ctx->stream, ctx->buf[0], ctx->buf[1],
+        hipLaunchKernelGGL((rk45_attempt_kernel<BLK, CPT, LAYOUT_TILED, VD>), dim3((unsigned)nb), dim3(BLK), 0, ctx->stream, ctx->buf[0], ctx->buf[1],
                            ctx->buf[2], ctx->buf[3], ctx->dconsts, ctx->slab, ctx->dctrl, ctx->part);
     else
-        hipLaunchKernelGGL((rk45_attempt_kernel<BLK, CPT, LAYOUT_FIELD_MAJOR>), dim3((unsigned)nb), dim3(BLK), 0, ctx->stream, ctx->buf[0],
+        hipLaunchKernelGGL((rk45_attempt_kernel<BLK, CPT, LAYOUT_FIELD_MAJOR, VD>), dim3((unsigned)nb), dim3(BLK), 0, ctx->stream, ctx->buf[0],
                            ctx->buf[1], ctx->buf[2], ctx->buf[3], ctx->dconsts, ctx->slab, ctx->dctrl, ctx->part);
 }
 
@@ -459,7 +484,7 @@ static int launch_attempt(marl_ctx* ctx, int v, int layout)
 {
     const int64_t nb = rk45_blocks(ctx, v);
     switch (v) {
-        case 0: launch_attempt_t<256, 1>(ctx, nb, layout); break;
+        case 0: if (ctx->var_dphi) launch_attempt_t<256, 1, true>(ctx, nb, layout); else launch_attempt_t<256, 1>(ctx, nb, layout); break;
         case 1: launch_attempt_t<256, 2>(ctx, nb, layout); break;
         case 2: launch_attempt_t<512, 1>(ctx, nb, layout); break;
         case 3: launch_attempt_t<128, 1>(ctx, nb, layout); break;
@@ -471,15 +496,15 @@ static int launch_attempt(marl_ctx* ctx, int v, int layout)
     return 0;
 }
 
-template <int BLK, int CPT>
+template <int BLK, int CPT, bool VD = false>
 static void launch_dense_t(marl_ctx* ctx, int64_t nb, int layout, const double* yold, const double* fold, double h,
                            const DenseWeights& dw, double* yout)
 {
     if (layout == LAYOUT_TILED)
-        hipLaunchKernelGGL((rk45_dense_kernel<BLK, CPT, LAYOUT_TILED>), dim3((unsigned)nb), dim3(BLK), 0, ctx->stream, yold, fold, ctx->dconsts,
+        hipLaunchKernelGGL((rk45_dense_kernel<BLK, CPT, LAYOUT_TILED, VD>), dim3((unsigned)nb), dim3(BLK), 0, ctx->stream, yold, fold, ctx->dconsts,
                            ctx->slab, h, dw, yout, ctx->part);
     else
-        hipLaunchKernelGGL((rk45_dense_kernel<BLK, CPT, LAYOUT_FIELD_MAJOR>), dim3((unsigned)nb), dim3(BLK), 0, ctx->stream, yold, fold,
+        hipLaunchKernelGGL((rk45_dense_kernel<BLK, CPT, LAYOUT_FIELD_MAJOR, VD>), dim3((unsigned)nb), dim3(BLK), 0, ctx->stream, yold, fold,
                            ctx->dconsts, ctx->slab, h, dw, yout, ctx->part);
 }
 
@@ -509,7 +534,7 @@ static int dense_eval(marl_ctx* ctx, int v, int layout, bool small, const Rk45Ct
     const double* fold = small ? ctx->buf[3] : ctx->buf[2 + (c.cur ^ 1)];
     const int64_t nb = rk45_blocks(ctx, v);
     switch (v) {
-        case 0: launch_dense_t<256, 1>(ctx, nb, layout, yold, fold, c.h_prev, dw, yout); break;
+        case 0: if (ctx->var_dphi) launch_dense_t<256, 1, true>(ctx, nb, layout, yold, fold, c.h_prev, dw, yout); else launch_dense_t<256, 1>(ctx, nb, layout, yold, fold, c.h_prev, dw, yout); break;
         case 1: launch_dense_t<256, 2>(ctx, nb, layout, yold, fold, c.h_prev, dw, yout); break;
         case 2: launch_dense_t<512, 1>(ctx, nb, layout, yold, fold, c.h_prev, dw, yout); break;
         case 3: launch_dense_t<128, 1>(ctx, nb, layout, yold, fold, c.h_prev, dw, yout); break;

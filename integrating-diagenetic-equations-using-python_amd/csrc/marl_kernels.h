@@ -52,7 +52,8 @@ __device__ __forceinline__ double nanmax(double a, double b) { return (a > b || 
 // REUSE = false: no transcendental cache (one-workgroup sweeps on coarse grids, where the stage displacements
 // are far outside the expansions' range).  The cache (marl_math.h, PointCache) also needs its LDS slots to fit
 // the 64 KB a workgroup may declare: wide variants (512 threads, several cells per thread) run without it.
-template <int BLK, int CPT, bool REUSE = true>
+// VD: the time-varying porosity diffusion coefficient (marl_params.dPhi_variable), see marl_math.h.
+template <int BLK, int CPT, bool REUSE = true, bool VD = false>
 struct StencilBlock {
     static constexpr int WIN = BLK * CPT;
     static constexpr int NSIDE = (CPT == 1) ? 1 : 2;
@@ -114,7 +115,7 @@ struct StencilBlock {
         PointLocal pl[CPT];
 #pragma unroll
         for (int c = 0; c < CPT; c++) {
-            point_local<CACHE ? MODE : TR_PLAIN>(ys[c], (zone_mask >> c) & 1u, K, C, T, pl[c], aux[c], cache[CACHE ? c : 0], reuse_live[c]);
+            point_local<CACHE ? MODE : TR_PLAIN, (CACHE && CACHE_LDS) ? WIN : 0, VD>(ys[c], (zone_mask >> c) & 1u, K, C, T, pl[c], aux[c], cache[CACHE ? c : 0], reuse_live[c]);
             // one cell at a time: interleaving the cells' evaluations doubles the live temporaries (spills at CPT >= 2)
             if constexpr (CPT > 1) __builtin_amdgcn_sched_barrier(0);
         }
@@ -149,7 +150,7 @@ struct StencilBlock {
                     for (int f = 0; f < NF; f++) um[f] = ghost_lower(C->bc[f], ys[c][f]);
                 }
             }
-            point_rates(ys[c], um, up, K, T, pl[c], k[c]);
+            point_rates<VD>(ys[c], um, up, K, T, pl[c], k[c]);
         }
     }
 };
@@ -201,7 +202,7 @@ __device__ __forceinline__ void block_reduce(double (&q)[NQ], double* scratch)
 // Stand-alone RHS: dydt = f(y).  The drop-in for the reference's fun / fun_numba callable
 // (marlpde/LHeureux_model.py:162, :290).  One thread per cell, neighbours straight from L1/L2.
 // ---------------------------------------------------------------------------------------------
-template <int LAYOUT>
+template <int LAYOUT, bool VD = false>
 __global__ void __launch_bounds__(256) rhs_kernel(const double* __restrict__ y, double* __restrict__ dydt,
                                                   const DevConsts* __restrict__ consts, Slab S, int64_t inst_stride)
 {
@@ -225,7 +226,7 @@ __global__ void __launch_bounds__(256) rhs_kernel(const double* __restrict__ y, 
     const HotConsts K = load_hot(&C);
     PointCache<0> pc;
     bool live = false;
-    rhs_point<TR_PLAIN>(uc, um, up, g >= C.mask_lo && g < C.mask_hi, K, &C, T, r, aux, pc, live);
+    rhs_point<TR_PLAIN, 0, VD>(uc, um, up, g >= C.mask_lo && g < C.mask_hi, K, &C, T, r, aux, pc, live);
 #pragma unroll
     for (int f = 0; f < NF; f++) dydt[at<LAYOUT>(f, l, S.ld)] = r[f];
 }
@@ -362,7 +363,7 @@ __device__ unsigned long long marl_lab_clock[3 * 16384];
 #endif
 // One cell per thread: 4 waves per SIMD (<= 128 VGPRs; 4 workgroups of 256 share the CU's 160 KB of LDS).
 // Variants with more cells per thread keep the compiler's own choice.
-template <int BLK, int CPT, int LAYOUT, int NSTEPS>
+template <int BLK, int CPT, int LAYOUT, int NSTEPS, bool VD = false>
 __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(CPT == 1 ? 4 : 1, 8))) rk4_fused_kernel(const double* __restrict__ yin, double* __restrict__ yout,
                                                         const DevConsts* __restrict__ consts, Slab S, double dt)
 {
@@ -373,7 +374,8 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(CPT ==
     constexpr int WIN = BLK * CPT;
     constexpr int V = WIN - 2 * H;
     static_assert(V > 0, "window too small for the fused halo");
-    __shared__ double lds[StencilBlock<BLK, CPT>::LDS_DOUBLES];
+    using SB = StencilBlock<BLK, CPT, true, VD>;
+    __shared__ double lds[SB::LDS_DOUBLES];
     const DevConsts& C = consts[0];
 
     const int64_t w0 = S.out_lo + (int64_t)blockIdx.x * V - H;  // window start, local index
@@ -381,7 +383,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(CPT ==
     double y[CPT][NF], ys[CPT][NF], k[CPT][NF], acc[CPT][NF];
     PointAux aux[CPT];
     load_cells<CPT, LAYOUT>(yin, l0, S, C, y);              // in flight while the tables are staged
-    StencilBlock<BLK, CPT> sb(lds, l0 + S.goff, consts);   // (table copy + barrier inside)
+    SB sb(lds, l0 + S.goff, consts);   // (table copy + barrier inside)
     const double h2 = 0.5 * dt, h6 = dt / 6.0;
 
 #pragma unroll 1
@@ -669,7 +671,7 @@ __device__ __forceinline__ double dp45_err2(double esum, double h, double y, dou
 // (y, f) from buffer `cur`, writes (y_new, f_new) into the other buffer and one reduction record per
 // block; rk45_control_kernel then accepts (flips `cur`) or rejects.  FSAL: f_new becomes K1.
 // ---------------------------------------------------------------------------------------------
-template <int BLK, int CPT, int LAYOUT>
+template <int BLK, int CPT, int LAYOUT, bool VD = false>
 __global__ void __launch_bounds__(BLK) rk45_attempt_kernel(double* __restrict__ Y0, double* __restrict__ Y1,
                                                            double* __restrict__ F0, double* __restrict__ F1,
                                                            const DevConsts* __restrict__ consts, Slab S,
@@ -678,7 +680,8 @@ __global__ void __launch_bounds__(BLK) rk45_attempt_kernel(double* __restrict__ 
     constexpr int H = 6;
     constexpr int WIN = BLK * CPT;
     constexpr int V = WIN - 2 * H;
-    __shared__ double lds[StencilBlock<BLK, CPT>::LDS_DOUBLES];
+    using SB = StencilBlock<BLK, CPT, true, VD>;
+    __shared__ double lds[SB::LDS_DOUBLES];
     if (ctrl->status != ST_RUNNING) return;
     const DevConsts& C = consts[0];
     const int cur = ctrl->cur;
@@ -701,8 +704,8 @@ __global__ void __launch_bounds__(BLK) rk45_attempt_kernel(double* __restrict__ 
 #pragma unroll
         for (int f = 0; f < NF; f++) k1[c][f] = in ? fin[at<LAYOUT>(f, l, S.ld)] : 0.0;
     }
-    StencilBlock<BLK, CPT> sb(lds, l0 + S.goff, consts);   // (table copy + barrier inside)
-    dp45_attempt<BLK, CPT>(sb, h, y, k1, yn, k7, esum, aux);
+    SB sb(lds, l0 + S.goff, consts);   // (table copy + barrier inside)
+    dp45_attempt<BLK, CPT, false, SB>(sb, h, y, k1, yn, k7, esum, aux);
 
     double q[NQ];
     monitors_init(q);
@@ -739,7 +742,7 @@ __device__ __forceinline__ void uw_point(double Phi, const DevConsts& C, const T
 // Dense output of the step that starts at (yold, fold) with size h: replays the step's stages and
 // writes  y(t_old + x h) = y_old + h sum_j w_j(x) K_j  (t_eval samples, ivp.py:706-723) and/or the
 // monitors record of that state (event root finding, ivp.py:51-76).  yout may be NULL.
-template <int BLK, int CPT, int LAYOUT>
+template <int BLK, int CPT, int LAYOUT, bool VD = false>
 __global__ void __launch_bounds__(BLK) rk45_dense_kernel(const double* __restrict__ yold, const double* __restrict__ fold,
                                                          const DevConsts* __restrict__ consts, Slab S, double h,
                                                          DenseWeights dw, double* __restrict__ yout, double* __restrict__ part)
@@ -747,11 +750,12 @@ __global__ void __launch_bounds__(BLK) rk45_dense_kernel(const double* __restric
     constexpr int H = 6;
     constexpr int WIN = BLK * CPT;
     constexpr int V = WIN - 2 * H;
-    __shared__ double lds[StencilBlock<BLK, CPT>::LDS_DOUBLES];
+    using SB = StencilBlock<BLK, CPT, true, VD>;
+    __shared__ double lds[SB::LDS_DOUBLES];
     const DevConsts& C = consts[0];
     const int64_t w0 = S.out_lo + (int64_t)blockIdx.x * V - H;
     const int64_t l0 = w0 + (int64_t)threadIdx.x * CPT;
-    StencilBlock<BLK, CPT> sb(lds, l0 + S.goff, consts);
+    SB sb(lds, l0 + S.goff, consts);
     double y[CPT][NF], k1[CPT][NF], yn[CPT][NF], k7[CPT][NF], dsum[CPT][NF];
     PointAux aux[CPT];
     load_cells<CPT, LAYOUT>(yold, l0, S, C, y);
@@ -762,7 +766,7 @@ __global__ void __launch_bounds__(BLK) rk45_dense_kernel(const double* __restric
 #pragma unroll
         for (int f = 0; f < NF; f++) k1[c][f] = in ? fold[at<LAYOUT>(f, l, S.ld)] : 0.0;
     }
-    dp45_attempt<BLK, CPT, true>(sb, h, y, k1, yn, k7, dsum, aux, dw);
+    dp45_attempt<BLK, CPT, true, SB>(sb, h, y, k1, yn, k7, dsum, aux, dw);
     double q[NQ];
     monitors_init(q);
 #pragma unroll
@@ -855,12 +859,12 @@ __global__ void __launch_bounds__(256) slab_copy_kernel(double* __restrict__ Y0,
 // on-chip for the whole integration; global memory is touched at entry and exit only.
 //   Y: [batch][5][N] field-major per instance (the reference's layout, one instance after another).
 // ---------------------------------------------------------------------------------------------
-template <int BLK, int CPT>
+template <int BLK, int CPT, bool VD = false>
 __global__ void __launch_bounds__(BLK) rk45_sweep_kernel(double* __restrict__ Y, const DevConsts* __restrict__ consts,
                                                          Rk45Ctrl* __restrict__ ctrls, int64_t N,
                                                          double* __restrict__ Yold, double* __restrict__ Fold)
 {
-    using SB = StencilBlock<BLK, CPT, false>;
+    using SB = StencilBlock<BLK, CPT, false, VD>;
     __shared__ double lds[SB::LDS_DOUBLES];
     __shared__ Rk45Ctrl sc;
     const DevConsts& C = consts[blockIdx.x];
@@ -930,11 +934,11 @@ __global__ void __launch_bounds__(BLK) rk45_sweep_kernel(double* __restrict__ Y,
     }
 }
 
-template <int BLK, int CPT>
+template <int BLK, int CPT, bool VD = false>
 __global__ void __launch_bounds__(BLK) rk4_sweep_kernel(double* __restrict__ Y, const DevConsts* __restrict__ consts,
                                                         const double* __restrict__ dts, int64_t N, int64_t nsteps)
 {
-    using SB = StencilBlock<BLK, CPT, false>;
+    using SB = StencilBlock<BLK, CPT, false, VD>;
     __shared__ double lds[SB::LDS_DOUBLES];
     const DevConsts& C = consts[blockIdx.x];
     double* yg = Y + (int64_t)blockIdx.x * NF * N;

@@ -45,8 +45,11 @@ struct HotConsts {
     double Dal;                      // Da * lambda_
     double rr10;                     // 10 * rhorat
     double dPhi_dx2;                 // dPhi / dx^2
+    double auxcon;                   // :65-66 (the time-varying porosity diffusion coefficient, dPhi_variable)
     int32_t fv;                      // FV_switch
     int32_t generic_p0;              // some exponent <= 0, i.e. some pow(0, e) != 0: take the general combination
+    int32_t var_dphi;                // marl_params.dPhi_variable (host side: selects the VD kernel instantiation)
+    int32_t reserved;
 };
 
 struct DevConsts {
@@ -237,7 +240,8 @@ struct PointLocal {
 // instance's full constant block (cold parts are read from memory only on rare paths).
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wsometimes-uninitialized"  // den ... tA are set on exactly one of the two paths below
-template <int MODE, int STRIDE>
+// VD: the time-varying porosity diffusion coefficient (marl_params.dPhi_variable) - compiled in only where asked for.
+template <int MODE, int STRIDE, bool VD = false>
 __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask, const HotConsts& K, const DevConsts* __restrict__ C,
                                             const Tables& T, PointLocal& pl, PointAux& aux, PointCache<STRIDE>& pc, bool& live)
 {
@@ -368,6 +372,11 @@ __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask
     const double U = __builtin_fma(t2 * Phi, invom, K.presum);
     aux.U = U;
     aux.W = W;
+    double wpe = fabs(W) * K.pe_Phi;   // |Peclet_Phi| (:452)
+    if constexpr (VD) {   // dPhi = auxcon F Phi^3/(1-Phi) (:430, commented out in the reference) instead of dPhi_fixed
+        const double dPhi = K.auxcon * (F * (Phi * Phi)) * (Phi * invom);
+        wpe = fabs(W) * (K.pe_Phi * (K.dPhi * rcp_nr(dPhi)));   // delta_x / (2 dPhi)
+    }
 
     // ---- reaction terms (:479-493)
     const double DA = K.Da * (CA * tA);          // Da coA
@@ -384,7 +393,7 @@ __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask
     const double Wd = W * den;
     bool fv_active = false;
     if (fv_check) {
-        const double pmax = fmax(fabs(Wd) * K.pe_smax, fabs(W) * K.pe_Phi);
+        const double pmax = fmax(fabs(Wd) * K.pe_smax, wpe);
         fv_active = !(pmax < PECLET_MIN);
         if constexpr (MODE == TR_FILL || MODE == TR_AUTO) { if (!reuse) pc.fv_quiet = pmax < 0.9 * PECLET_MIN; }  // in range, Pe moves by < 1e-3 relative
     } else if constexpr (MODE == TR_FILL || MODE == TR_AUTO) {
@@ -406,6 +415,7 @@ __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask
 #pragma clang diagnostic pop
 
 // uc/um/up: values at cell i, i-1, i+1 (ghosts already substituted).  r: the five rates (LHeureux_model.py:498-520).
+template <bool VD = false>
 __device__ __forceinline__ void point_rates(const double (&uc)[NF], const double (&um)[NF], const double (&up)[NF],
                                             const HotConsts& K, const Tables& T, const PointLocal& pl, double (&r)[NF])
 {
@@ -414,6 +424,11 @@ __device__ __forceinline__ void point_rates(const double (&uc)[NF], const double
     return;
 #endif
     const double CA = uc[0], CC = uc[1], c = uc[2], o = uc[3], Phi = uc[4];
+    // dPhi = auxcon F Phi^3/(1-Phi) of this cell (VD only)
+    auto dPhi_cell = [&]() {
+        const double F = 1.0 - fast_exp(__builtin_fma(-10.0, pl.invPhi, 10.0), T);
+        return K.auxcon * (F * (Phi * Phi)) * (Phi * rcp_nr(1.0 - Phi));
+    };
     // ---- solids: upwinded one-sided difference (:372-384, :418-423).
     //   U > 0: -U (u - u[i-1])/dx;  else: -U (u[i+1] - u)/dx = -|U| (u - u[i+1])/dx  -> one difference, upwind neighbour
     r[0] = __builtin_fma(-pl.Ux, CA - (pl.upw ? um[0] : up[0]), pl.R0);
@@ -434,7 +449,8 @@ __device__ __forceinline__ void point_rates(const double (&uc)[NF], const double
         og = (o_f + o_b) * K.hdx;
     } else {
         const double W = pl.W, Wd = pl.Wd;
-        const double s_c = fv_sigma(Wd * K.pe_cCa, W, T), s_o = fv_sigma(Wd * K.pe_cCO3, W, T), s_p = fv_sigma(W * K.pe_Phi, W, T);
+        const double pe_Phi = VD ? K.pe_Phi * (K.dPhi * rcp_nr(dPhi_cell())) : K.pe_Phi;   // delta_x / (2 dPhi)
+        const double s_c = fv_sigma(Wd * K.pe_cCa, W, T), s_o = fv_sigma(Wd * K.pe_cCO3, W, T), s_p = fv_sigma(W * pe_Phi, W, T);
         cg = ((1.0 - s_c) * c_f + (1.0 + s_c) * c_b) * K.hdx;
         og = ((1.0 - s_o) * o_f + (1.0 + s_o) * o_b) * K.hdx;
         pg = ((1.0 - s_p) * p_f + (1.0 + s_p) * p_b) * K.hdx;
@@ -444,18 +460,24 @@ __device__ __forceinline__ void point_rates(const double (&uc)[NF], const double
     const double Ho = K.dCO3 * __builtin_fma(h2, og, pl.h1x * o_d);     // (:476-477)
     r[2] = __builtin_fma(-pl.W, cg, __builtin_fma(pl.invPhi, Hc, pl.G2));   // :506-509
     r[3] = __builtin_fma(-pl.W, og, __builtin_fma(pl.invPhi, Ho, pl.G3));   // :512-515
-    r[4] = __builtin_fma(-pg, pl.Q4, __builtin_fma(K.dPhi_dx2, p_d, pl.DaR));  // :518-520
+    double diffusion;   // dPhi * Phi_laplace + Da (1-Phi)(coA - lambda coC)
+    if constexpr (VD) {
+        diffusion = __builtin_fma(dPhi_cell() * K.inv_dx2, p_d, pl.DaR);
+    } else {
+        diffusion = __builtin_fma(K.dPhi_dx2, p_d, pl.DaR);
+    }
+    r[4] = __builtin_fma(-pg, pl.Q4, diffusion);  // :518-520
 }
 
 // Both phases back to back (stand-alone RHS).
-template <int MODE, int STRIDE>
+template <int MODE, int STRIDE, bool VD = false>
 __device__ __forceinline__ void rhs_point(const double (&uc)[NF], const double (&um)[NF], const double (&up)[NF],
                                           bool in_mask, const HotConsts& K, const DevConsts* __restrict__ C,
                                           const Tables& T, double (&r)[NF], PointAux& aux, PointCache<STRIDE>& pc, bool& live)
 {
     PointLocal pl;
-    point_local<MODE>(uc, in_mask, K, C, T, pl, aux, pc, live);
-    point_rates(uc, um, up, K, T, pl, r);
+    point_local<MODE, STRIDE, VD>(uc, in_mask, K, C, T, pl, aux, pc, live);
+    point_rates<VD>(uc, um, up, K, T, pl, r);
 }
 
 

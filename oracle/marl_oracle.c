@@ -131,7 +131,8 @@ static void orc_rhs(const marl_params *p, const orc_consts *c, int64_t N, const 
         const double W = c->presum - c->rhorat * pow(Phi[i], 2) * F;                        /* :425 */
         const double denominator = 1 - 2 * log(Phi[i]);                                     /* :428 */
         const double one_minus_Phi = 1 - Phi[i];                                            /* :429 */
-        const double dPhi = c->dPhi_fixed;                                                  /* :431 */
+        const double dPhi = p->dPhi_variable ? c->auxcon * F * pow(Phi[i], 3) / one_minus_Phi     /* :430 (commented out there) */
+                                             : c->dPhi_fixed;                               /* :431 */
 
         double sigma_cCa = 0, sigma_cCO3 = 0, sigma_Phi = 0;
         if (p->FV_switch) {                                                                 /* :433-458 */

@@ -55,6 +55,7 @@ def params_from_dict(p, length=None):
     blk.shallow_limit = float(p["ShallowLimit"]) / float(p["Xstar"])
     blk.deep_limit = float(p["DeepLimit"]) / float(p["Xstar"])
     blk.FV_switch = int(p["FV_switch"])
+    blk.dPhi_variable = int(p.get("dPhi_variable", 0))
     return blk
 
 
@@ -67,6 +68,7 @@ def params_from_model(eq, inst=0):
     blk.shallow_limit = float(d["ShallowLimit"]) / float(d["Xstar"])
     blk.deep_limit = float(d["DeepLimit"]) / float(d["Xstar"])
     blk.FV_switch = int(d["FV_switch"])
+    blk.dPhi_variable = int(d.get("dPhi_variable", 0))
     return blk
 
 

@@ -550,3 +550,34 @@ def test_integrate_equations_stores_results_like_the_reference(tmp_path):
     assert z["solutions"].shape == (5, 200, 3) and np.array_equal(z["times"], trk["t_eval"])
     assert all(f"event_{i}" in z for i in range(7)) and float(z["attr_Phi0"]) == 0.6
     assert np.array_equal(z["solutions"][:, :, -1], last) and covered == pytest.approx(13190.0 * 2e-3)
+
+
+@pytest.mark.parametrize("name,N,fv,dtf", [("A", 200, 1, 0.2), ("default", 64, 1, 0.2), ("matlab", 1000, 0, 0.2), ("default", 8, 1, 0.01),
+                                            ("A", 3000, 1, 0.2)])   # 3000: the multi-workgroup fused kernels
+def test_time_varying_porosity_diffusion_against_oracle(torch_cuda, oracle, name, N, fv, dtf):
+    """SURVEY 8(f) rank 4 (`dPhi_variable`): RHS, fused RK4 and RK45 with dPhi = auxcon F Phi^3/(1-Phi).  The porosity
+    Peclet number is 0.9 (N = 200) ... 22 (N = 8) here: the Fiadeiro-Veronis weight of Phi is active and uses the
+    cell's own dPhi.  Parity is against the oracle only (the reference keeps this variant commented out)."""
+    torch = torch_cuda
+    p = scenario(name, N, fv=fv) | {"dPhi_variable": True}
+    eq = make_model(p)
+    eq.use_stream(torch.cuda.current_stream().cuda_stream)
+    P = oracle.params_from_model(eq)
+    assert P.dPhi_variable == 1
+    y = noisy_state(p, N, seed=5, sigma=0.03)
+    ref = oracle.rhs(P, N, y)
+    assert rel_to_max(eq.fun(0.0, y), ref) <= RHS_TOL
+    plain = make_model(scenario(name, N, fv=fv))
+    assert rel_to_max(plain.fun(0.0, y), ref) > 1e-6            # not the fixed-coefficient result
+    plain.close()
+    y = synthetic_state(p, N, amplitude=0.05)
+    dx2 = (eq.Depths.length / N) ** 2
+    ref4 = oracle.rk4(P, N, y, dtf * dx2, 25)
+    assert np.all(np.isfinite(ref4))
+    assert rel_to_max(eq.integrate_rk4(y, dtf * dx2, 25), ref4) <= RUN_TOL
+    yref, st, *_ = oracle.rk45(P, N, y, 0.0, 40 * dx2, 0.5 * dx2, 1e-5, 1e-7)
+    yd = torch.from_numpy(y).cuda()
+    res = eq.integrate_rk45_device(yd.data_ptr(), (0.0, 40 * dx2), 0.5 * dx2, 1e-5, 1e-7)
+    assert (res.status, res.n_accepted, res.n_rejected) == (0, st.n_accepted, st.n_rejected)
+    assert rel_to_max(yd.cpu().numpy(), yref) <= RUN_TOL
+    eq.close()
