@@ -280,7 +280,7 @@ def main():
         traffic, traffic_note = None, "no PMC summary committed for this kernel variant"
         pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
         if per_launch and args.workload == "rk4_single" and N == (1 << 20) and os.path.exists(pmc_file):
-            k = json.load(open(pmc_file))["kernels"].get("void marl::rk4_fused_kernel<256, 1, 1, 4>")
+            k = next((v for n, v in json.load(open(pmc_file))["kernels"].items() if "rk4_fused_kernel<256, 1, 1, 4" in n), None)
             if k:
                 traffic = k["hbm_bytes_per_launch"]
                 traffic_note = ("HBM bytes per launch (4 RK4 steps) from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
