@@ -63,9 +63,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the package has no CPU path)"
+    # rehearsal of the N > 1 path on a one-GPU box: MARL_BENCH_BACKEND=gloo MARL_BENCH_ONE_DEVICE=1 (all ranks on cuda:0)
+    if os.environ.get("MARL_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("MARL_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     stream = torch.cuda.current_stream()
 
     def barrier():
@@ -219,7 +226,7 @@ def main():
         extra.update(info)
 
     # max over ranks of the wall time of the timed region
-    wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda" if (world == 1 or dist.get_backend() == "nccl") else "cpu")
     if world > 1:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
     wall_max = float(wall_t.item())
