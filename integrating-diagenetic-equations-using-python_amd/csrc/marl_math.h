@@ -298,8 +298,13 @@ __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask
                 ex = e0 * __builtin_fma(da, __builtin_fma(da, __builtin_fma(da, 1.0 / 6, 0.5), 1.0), 1.0);
                 tC = tC0 * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.0 / 6, 0.5), 1.0), 1.0);
             }
-            fv_check = fv_check && !pc.fv_quiet;
-            if (fv_check) den = rcp_nr(invden);   // only the Peclet numbers need den itself
+            // wave-uniform on purpose: a per-lane condition is if-converted, and the Peclet test (with the reciprocal
+            // that recovers den) would then run in every evaluation
+            fv_check = fv_check && __builtin_amdgcn_ballot_w64(!pc.fv_quiet) != 0;
+            if (fv_check) {
+                asm volatile("");
+                den = rcp_nr(invden);   // only the Peclet numbers need den itself
+            }
         }
     }
     if (!reuse) {
@@ -390,17 +395,19 @@ __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask
     pl.R1 = __builtin_fma(CC, DmD, DC);
 
     // ---- Fiadeiro-Veronis weights (:433-462) all vanish when every |Pe| < PECLET_MIN (always on fine grids)
-    const double Wd = W * den;
     bool fv_active = false;
-    if (fv_check) {
+    pl.Wd = 0.0;
+    if (fv_check) {   // wave-uniform
+        asm volatile("");   // a real branch (its five cheap operations would otherwise be speculated into every evaluation)
+        const double Wd = W * den;
         const double pmax = fmax(fabs(Wd) * K.pe_smax, wpe);
         fv_active = !(pmax < PECLET_MIN);
+        pl.Wd = Wd;
         if constexpr (MODE == TR_FILL || MODE == TR_AUTO) { if (!reuse) pc.fv_quiet = pmax < 0.9 * PECLET_MIN; }  // in range, Pe moves by < 1e-3 relative
     } else if constexpr (MODE == TR_FILL || MODE == TR_AUTO) {
         if (!reuse) pc.fv_quiet = true;  // FV_switch off
     }
     pl.fv_active = fv_active;
-    pl.Wd = Wd;
     pl.W = W;
     pl.invPhi = invPhi;
     const double DaRi = DaR * invPhi;
