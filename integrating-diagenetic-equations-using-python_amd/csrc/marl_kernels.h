@@ -150,7 +150,7 @@ struct StencilBlock {
                     for (int f = 0; f < NF; f++) um[f] = ghost_lower(C->bc[f], ys[c][f]);
                 }
             }
-            point_rates<VD>(ys[c], um, up, K, T, pl[c], k[c]);
+            point_rates<VD>(ys[c], um, up, K, T, pl[c], k[c], CPT == 1 ? need_right_solids : true);
         }
     }
 };

@@ -422,9 +422,10 @@ __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask
 #pragma clang diagnostic pop
 
 // uc/um/up: values at cell i, i-1, i+1 (ghosts already substituted).  r: the five rates (LHeureux_model.py:498-520).
+// mixed_upwind (wave-uniform): false promises pl.upw in every lane of the wave - up[0], up[1] are then not read.
 template <bool VD = false>
 __device__ __forceinline__ void point_rates(const double (&uc)[NF], const double (&um)[NF], const double (&up)[NF],
-                                            const HotConsts& K, const Tables& T, const PointLocal& pl, double (&r)[NF])
+                                            const HotConsts& K, const Tables& T, const PointLocal& pl, double (&r)[NF], bool mixed_upwind = true)
 {
 #ifdef MARL_ABLATE_CORE
     for (int f = 0; f < NF; f++) r[f] = (up[f] - um[f]) * K.hdx * 1e-9;
@@ -438,8 +439,14 @@ __device__ __forceinline__ void point_rates(const double (&uc)[NF], const double
     };
     // ---- solids: upwinded one-sided difference (:372-384, :418-423).
     //   U > 0: -U (u - u[i-1])/dx;  else: -U (u[i+1] - u)/dx = -|U| (u - u[i+1])/dx  -> one difference, upwind neighbour
-    r[0] = __builtin_fma(-pl.Ux, CA - (pl.upw ? um[0] : up[0]), pl.R0);
-    r[1] = __builtin_fma(-pl.Ux, CC - (pl.upw ? um[1] : up[1]), pl.R1);
+    if (mixed_upwind) {   // wave-uniform: some lane has U <= 0
+        asm volatile("");
+        r[0] = __builtin_fma(-pl.Ux, CA - (pl.upw ? um[0] : up[0]), pl.R0);
+        r[1] = __builtin_fma(-pl.Ux, CC - (pl.upw ? um[1] : up[1]), pl.R1);
+    } else {              // burial everywhere (the normal case): no per-lane selects
+        r[0] = __builtin_fma(-pl.Ux, CA - um[0], pl.R0);
+        r[1] = __builtin_fma(-pl.Ux, CC - um[1], pl.R1);
+    }
 
     // ---- solutes and porosity.
     // one-sided differences (x dx): back = u - u[i-1], forw = u[i+1] - u (:372-384) - both exact for smooth fields

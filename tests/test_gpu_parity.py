@@ -581,3 +581,31 @@ def test_time_varying_porosity_diffusion_against_oracle(torch_cuda, oracle, name
     assert (res.status, res.n_accepted, res.n_rejected) == (0, st.n_accepted, st.n_rejected)
     assert rel_to_max(yd.cpu().numpy(), yref) <= RUN_TOL
     eq.close()
+
+
+@pytest.mark.parametrize("N", [3000, 700])
+def test_mixed_upwind_direction_inside_waves(torch_cuda, oracle, N):
+    """The fused kernels skip the upwind selects (and the right-hand LDS reads of the solids) when every lane of a
+    wave has U > 0.  A 15 % porosity modulation makes U change sign every ~40 cells in the default scenario
+    (presum = -3.2): waves mix both directions and must take the per-lane selects."""
+    torch = torch_cuda
+    p = scenario("default", N)
+    eq = make_model(p)
+    eq.use_stream(torch.cuda.current_stream().cuda_stream)
+    P = oracle.params_from_model(eq)
+    y = synthetic_state(p, N, amplitude=0.15, waves=N // 75)
+    Phi = y.reshape(5, N)[4]
+    U = eq.presum + eq.rhorat * Phi ** 3 * (1 - np.exp(10 - 10 / Phi)) / (1 - Phi)
+    assert 0.2 < np.mean(U > 0) < 0.8
+    assert rel_to_max(eq.fun(0.0, y), oracle.rhs(P, N, y)) <= RHS_TOL
+    dx2 = (eq.Depths.length / N) ** 2
+    ref = oracle.rk4(P, N, y, 0.1 * dx2, 12)
+    yd = torch.from_numpy(y).cuda()
+    eq.integrate_rk4_device(yd.data_ptr(), 0.1 * dx2, 12)
+    assert rel_to_max(yd.cpu().numpy(), ref) <= RUN_TOL
+    yref, st, *_ = oracle.rk45(P, N, y, 0.0, 20 * dx2, 0.2 * dx2, 1e-5, 1e-7)
+    yd = torch.from_numpy(y).cuda()
+    res = eq.integrate_rk45_device(yd.data_ptr(), (0.0, 20 * dx2), 0.2 * dx2, 1e-5, 1e-7)
+    assert (res.status, res.n_accepted, res.n_rejected) == (0, st.n_accepted, st.n_rejected)
+    assert rel_to_max(yd.cpu().numpy(), yref) <= RUN_TOL
+    eq.close()
