@@ -356,17 +356,16 @@ __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask
         // (whole waves skip the power), and caching it as well costs more registers / LDS reads than it saves
         const double O3 = O2 * K.KRat;
         const bool under = O3 < 1.0;
-        const double msel = under ? K.m2 : K.m1;
         tA = O3 - O3;                               // 0, or NaN for a non-finite O3 (keeps the reference's NaN visible)
         if (!under || in_mask) {
-            const double pwA = pow_sat(fabs(O3 - 1.0), msel, T);
+            const double pwA = pow_sat(fabs(O3 - 1.0), under ? K.m2 : K.m1, T);
             tA = (under ? 1.0 : -K.nu1) * pwA;      // (1-O3)^m2 * mask  |  -nu1 (O3-1)^m1
         }
         if (K.generic_p0) {
             asm volatile("");  // a real branch, as above
             const double z1 = C->p0_m1, z2 = C->p0_m2;
             const double mask = in_mask ? 1.0 : 0.0;
-            const double pa = (O3 == 1.0) ? (under ? z2 : z1) : ((!under || in_mask) ? fast_exp(msel * fast_log(fabs(O3 - 1.0), T), T) : 0.0);
+            const double pa = (O3 == 1.0) ? (under ? z2 : z1) : ((!under || in_mask) ? fast_exp((under ? K.m2 : K.m1) * fast_log(fabs(O3 - 1.0), T), T) : 0.0);
             tA = under ? pa * mask - K.nu1 * z1 : z2 * mask - K.nu1 * pa;
         }
     }
