@@ -1,8 +1,8 @@
 // marl_math.h - device-side point evaluation of the five-field L'Heureux RHS (gfx950 only).
 //
-// One call of rhs_point() evaluates what one iteration of the reference's depth loop
-// computes (marlpde/LHeureux_model.py:413-520, Appendix A of SURVEY.md) for one cell, given the
-// cell's five values and those of its two neighbours.  The 13 separate stencil passes of the
+// point_local() + point_rates() (together: rhs_point()) evaluate what one iteration of the reference's
+// depth loop computes (marlpde/LHeureux_model.py:413-520, Appendix A of SURVEY.md) for one cell, given the
+// cell's five values (own-cell phase) and those of its two neighbours (stencil phase).  The 13 separate stencil passes of the
 // reference (:372-384) are folded in; virtual (ghost) cells are synthesised by the caller with
 // ghost_lower()/ghost_upper() following the py-pde boundary rules the reference configures at
 // LHeureux_model.py:26-30.
@@ -17,7 +17,9 @@
 //   * exp and log are table-driven (3 KB of tables in LDS, ~20-25 instructions each instead of OCML's
 //     ~40 / ~96); pow(b, e) for the kinetics exponents is exp(e*log b) (error analysis in DESIGN.md);
 //   * coth(Pe) - 1/Pe is 1 + 2/(e^(2Pe) - 1) - 1/Pe and only taken in the mid Peclet range; the
-//     branch is wave-uniform in practice (hard part 1c).
+//     branch is wave-uniform in practice (hard part 1c);
+//   * later Runge-Kutta stages expand the transcendentals around an earlier evaluation (TR_* modes below);
+//   * rare paths sit behind real wave-uniform branches (`asm volatile("")` stops their speculation).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
