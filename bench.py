@@ -282,7 +282,7 @@ def main():
     if rank == 0:
         # dominant kernel: algorithmic bytes per launch / average launch duration (HIP events around the timed
         # region on the launch stream; launches are back to back, so gaps count against the kernel)
-        per_launch = {"rk4_single": 4 if (N > 131072 and args.variant < 0) else None}.get(args.workload)
+        per_launch = {"rk4_single": 4 if (N > 262144 and args.variant < 0) else None}.get(args.workload)
         achieved = BYTES_PER_POINT_STEP * units / (ev_ms * 1e-3) / 1e9  # GB/s
         traffic, traffic_note = None, "no PMC summary committed for this kernel variant"
         pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")

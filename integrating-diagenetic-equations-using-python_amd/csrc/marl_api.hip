@@ -386,7 +386,7 @@ static int default_rk4_variant(const marl_ctx* ctx)
     if (ctx->var_dphi) return kVdRk4Variant;
     if (ctx->rk4_variant >= 0 && ctx->rk4_variant < kNumRk4Variants) return (int)ctx->rk4_variant;
     const int64_t n = ctx->slab.out_hi - ctx->slab.out_lo;
-    return n <= 131072 ? 5 : 10;  // small grids: 8 steps/launch on 128-thread blocks (launch bound); large: 4 steps/launch
+    return n <= 262144 ? 11 : 10;  // 256-thread blocks; 8 steps per launch while the launch boundary matters, 4 beyond (tools/variant_sweep.sh)
 }
 
 // y (device, `layout`) advanced in place; `tmp` is a second buffer of the same size
