@@ -609,3 +609,33 @@ def test_mixed_upwind_direction_inside_waves(torch_cuda, oracle, N):
     assert (res.status, res.n_accepted, res.n_rejected) == (0, st.n_accepted, st.n_rejected)
     assert rel_to_max(yd.cpu().numpy(), yref) <= RUN_TOL
     eq.close()
+
+
+def test_config3_full_size_sweep_properties(torch_cuda, oracle):
+    """BASELINE config 3 at its full size (4096 instances x N = 1024, RK45): size-independent properties instead of
+    4096 oracle runs - instances with equal parameters end bit-identical wherever they sit in the batch (the
+    16 x 16 x 16 grid is laid out twice over 8 distinct parameter sets), and sampled instances equal the oracle."""
+    torch = torch_cuda
+    from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
+    N, B, D = 1024, 4096, 8
+    base = scenario("default", N)
+    distinct = [{"Phi0": float(a), "PhiIni": float(b), "PhiNR": float(b), "k3": float(k), "k4": float(k)}
+                for a, b, k in zip(np.linspace(0.5, 0.8, D), np.linspace(0.8, 0.5, D), np.logspace(-2, -1, D))]
+    order = np.random.default_rng(11).integers(0, D, B)
+    eq = LMAHeureuxPorosityDiff.from_scenario(base, device=0, instances=[distinct[i] for i in order])
+    eq.use_stream(torch.cuda.current_stream().cuda_stream)
+    y0d = np.stack([synthetic_state(base | d, N, amplitude=0.02) for d in distinct])
+    dx2 = (eq.Depths.length / N) ** 2
+    yd = torch.from_numpy(y0d[order]).cuda()
+    res = eq.sweep_rk45_device(yd.data_ptr(), (0.0, 1.0), 0.5 * dx2, 1e-3, 1e-3, max_attempts=40)
+    torch.cuda.synchronize()
+    got = yd.cpu().numpy()
+    for i in range(D):
+        rows = np.flatnonzero(order == i)
+        assert len(rows) > 100
+        assert np.all(got[rows] == got[rows[0]]), i                       # bit-identical replicas
+        assert len({(res[r].n_accepted, res[r].n_rejected, res[r].t_reached) for r in rows}) == 1
+        yref, st, *_ = oracle.rk45(oracle.params_from_model(eq, int(rows[0])), N, y0d[i], 0.0, 1.0, 0.5 * dx2, 1e-3, 1e-3, max_attempts=40)
+        assert (res[rows[0]].status, res[rows[0]].n_accepted, res[rows[0]].n_rejected) == (2, st.n_accepted, st.n_rejected)
+        assert rel_to_max(got[rows[0]], yref) <= 1e-9
+    eq.close()
