@@ -356,18 +356,10 @@ def test_integrate_equations_rk45_against_reference_golden():
     print("max abs deviation from the reference golden per field:", np.max(np.abs(last - gold), axis=1))
 
 
-def test_domain_decomposition_slabs_on_one_gpu(torch_cuda, oracle):
-    """BASELINE config 5 logic on ONE GPU: three slab contexts stand for three ranks; strips and records are
-    moved by plain tensor copies where the multi-GPU driver (marlpde_amd/domain.py) uses RCCL send/recv and
-    all-gather.  Checks the slab kernels (pack / unpack / halo-consuming fused attempt / shared control)."""
-    torch = torch_cuda
+def _run_slabs(torch, p, N, P, y0, t1, h0, rtol, atol, max_attempts=0):
+    """Three slab contexts on ONE GPU stand for three ranks; strips and records are moved by plain tensor copies
+    where the multi-GPU driver (marlpde_amd/domain.py) uses RCCL send/recv and all-gather."""
     from marlpde_amd.domain import HALO, STRIP, HipSlabEngine, owned_slice, partition
-    N, P = 5000, 3
-    p = scenario("A", N)
-    y0 = synthetic_state(p, N, amplitude=0.05)
-    dx2 = ((p["max_depth"] / p["Xstar"]) / N) ** 2
-    t1, h0, rtol, atol = 40 * dx2, 0.5 * dx2, 1e-5, 1e-7
-    yref, st, *_ = oracle.rk45(oracle.params_from_dict(p), N, y0, 0.0, t1, h0, rtol, atol)
     parts = partition(N, P)
     eng = [HipSlabEngine(p, N, b, e, 0) for b, e in parts]
     ys = [torch.from_numpy(owned_slice(y0, N, b, e)).cuda() for b, e in parts]
@@ -400,7 +392,7 @@ def test_domain_decomposition_slabs_on_one_gpu(torch_cuda, oracle):
         eng[r].monitors(rec[r])
     gather()
     for r in range(P):
-        eng[r].init_control(recs, P, 0.0, t1, h0, rtol, atol, 0)
+        eng[r].init_control(recs, P, 0.0, t1, h0, rtol, atol, max_attempts)
     for _ in range(200):
         for _ in range(8):
             for r in range(P):
@@ -412,14 +404,50 @@ def test_domain_decomposition_slabs_on_one_gpu(torch_cuda, oracle):
         stats = [eng[r].status() for r in range(P)]
         if stats[0].status != 1:
             break
-    assert {(s.status, s.n_accepted, s.n_rejected, s.nfev, s.t) for s in stats} == {(0, st.n_accepted, st.n_rejected, st.nfev, t1)}
     for r in range(P):
         eng[r].store(ys[r])
     torch.cuda.synchronize()
     got = np.concatenate([y.cpu().numpy().reshape(5, -1) for y in ys], axis=1)
-    assert rel_to_max(got, yref.reshape(5, N)) <= RUN_TOL
     for e in eng:
         e.close()
+    return stats, got
+
+
+def test_domain_decomposition_slabs_on_one_gpu(torch_cuda, oracle):
+    """BASELINE config 5 logic on ONE GPU: checks the slab kernels (pack / unpack / halo-consuming fused attempt /
+    shared control) against the oracle's single-grid run, incl. rejected attempts."""
+    N, P = 5000, 3
+    p = scenario("A", N)
+    y0 = synthetic_state(p, N, amplitude=0.05)
+    dx2 = ((p["max_depth"] / p["Xstar"]) / N) ** 2
+    t1, h0, rtol, atol = 40 * dx2, 0.5 * dx2, 1e-5, 1e-7
+    yref, st, *_ = oracle.rk45(oracle.params_from_dict(p), N, y0, 0.0, t1, h0, rtol, atol)
+    stats, got = _run_slabs(torch_cuda, p, N, P, y0, t1, h0, rtol, atol)
+    assert {(s.status, s.n_accepted, s.n_rejected, s.nfev, s.t) for s in stats} == {(0, st.n_accepted, st.n_rejected, st.nfev, t1)}
+    assert rel_to_max(got, yref.reshape(5, N)) <= RUN_TOL
+
+
+def test_config5_full_size_decomposition_equals_single_grid(torch_cuda):
+    """BASELINE config 5 at its full size (N = 2^22, RK45): the decomposition is invisible - three slabs with
+    exchanged halos take the same accept/reject decisions as the single-grid integrator (itself checked against the
+    oracle at the sizes the oracle finishes) and reach the same state, for an attempt budget of 12."""
+    torch = torch_cuda
+    N, P, budget = 1 << 22, 3, 12
+    p = scenario("default", N)
+    y0 = synthetic_state(p, N, amplitude=0.01)
+    dx2 = ((p["max_depth"] / p["Xstar"]) / N) ** 2
+    t1, h0, rtol, atol = 1.0, 0.5 * dx2, 1e-3, 1e-3
+    eq = make_model(p)
+    eq.use_stream(torch.cuda.current_stream().cuda_stream)
+    yd = torch.from_numpy(y0).cuda()
+    res = eq.integrate_rk45_device(yd.data_ptr(), (0.0, t1), h0, rtol, atol, max_attempts=budget)
+    single = yd.cpu().numpy().reshape(5, N)
+    eq.close()
+    stats, got = _run_slabs(torch, p, N, P, y0, t1, h0, rtol, atol, max_attempts=budget)
+    assert res.status == 2 and res.n_accepted + res.n_rejected == budget and res.n_accepted >= 3
+    assert {(s.status, s.n_accepted, s.n_rejected) for s in stats} == {(2, res.n_accepted, res.n_rejected)}
+    assert {s.t for s in stats} == {res.t_reached}
+    assert np.max(np.abs(got - single)) <= 1e-13
 
 
 @pytest.mark.parametrize("name,gold_file,first_step", [("matlab", "ref_matlab_Phi_0.5_k3_k4_0.01.npy", 1e-6),
