@@ -49,7 +49,9 @@ const char* marl_last_error(const marl_ctx* ctx); /* ctx may be NULL: error of t
  * torch.cuda.current_stream().cuda_stream; NULL selects the default stream again). */
 int marl_set_stream(marl_ctx* ctx, void* hip_stream);
 int marl_synchronize(marl_ctx* ctx);
-/* Tuning knobs (kernel variant selection); unknown names are an error.  See DESIGN.md. */
+/* Tuning knobs; unknown names are an error.  See DESIGN.md.
+ *   rk4_variant, rk45_variant, sweep_variant (kernel shapes; -1 = default), host_layout (device layout used behind the
+ *   host-pointer entry points), poll_interval (attempts enqueued between status reads). */
 int marl_set_option(marl_ctx* ctx, const char* name, int64_t value);
 /* Derived constants of instance `inst` in the order of tests/golden/derived_constants.json:
  * delta_x nu1 nu2 KRat dCa dCO3 delta Da lambda_ auxcon rhorat0 rhorat presum F_fixed dPhi_fixed

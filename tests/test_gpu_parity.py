@@ -446,7 +446,7 @@ def test_config5_full_size_decomposition_equals_single_grid(torch_cuda):
     stats, got = _run_slabs(torch, p, N, P, y0, t1, h0, rtol, atol, max_attempts=budget)
     assert res.status == 2 and res.n_accepted + res.n_rejected == budget and res.n_accepted >= 3
     assert {(s.status, s.n_accepted, s.n_rejected) for s in stats} == {(2, res.n_accepted, res.n_rejected)}
-    assert {s.t for s in stats} == {res.t_reached}
+    assert all(s.t == pytest.approx(res.t_reached, rel=1e-12) for s in stats)   # (error-norm partial sums are grouped differently)
     assert np.max(np.abs(got - single)) <= 1e-13
 
 
