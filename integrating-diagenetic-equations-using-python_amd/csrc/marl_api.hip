@@ -984,7 +984,7 @@ int marl_slab_attempt(marl_ctx* ctx, double* rec_dev)
     const int64_t nb = rk45_blocks(ctx, v);
     if (int rc = ensure_part(ctx, (size_t)std::max<int64_t>(nb, 1024))) return rc;
     switch (v) {
-        case 0: launch_attempt_t<256, 1>(ctx, nb, LAYOUT_FIELD_MAJOR); break;
+        case 0: if (ctx->var_dphi) launch_attempt_t<256, 1, true>(ctx, nb, LAYOUT_FIELD_MAJOR); else launch_attempt_t<256, 1>(ctx, nb, LAYOUT_FIELD_MAJOR); break;
         case 1: launch_attempt_t<256, 2>(ctx, nb, LAYOUT_FIELD_MAJOR); break;
         case 2: launch_attempt_t<512, 1>(ctx, nb, LAYOUT_FIELD_MAJOR); break;
         default: launch_attempt_t<128, 1>(ctx, nb, LAYOUT_FIELD_MAJOR); break;

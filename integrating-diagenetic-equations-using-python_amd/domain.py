@@ -4,11 +4,11 @@ Not in the reference (it never decomposes the depth axis) - th
 One process per GPU (``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm).  Rank r owns the
 contiguous cells [N r / P, N (r+1) / P); its slab buffer carries ``halo`` cells of each neighbour.  A fused
 Dormand-Prince attempt consumes 6 cells of halo per side (marl_kernels.h), so ONE exchange per attempt
-suffices: 2 arrays (y_new, f_new) x 5 fields x halo cells = 480 B per side - pure latency, sent with paired
-``isend``/``irecv`` to the two depth neighbours only (a chain: each pair sits on its own xGMI link).  The step
-controller needs the global error norm: each rank reduces its cells to one 8-double record, the records are
-all-gathered and every rank combines them IN RANK ORDER, so all ranks take bit-identical accept/reject
-decisions.  No host synchronisation inside the loop: kernels and collectives are enqueued on one stream, the
+suffices: 2 arrays (y_new, f_new) x 5 fields x halo cells = 480 B per side.  The step controller needs the
+global error norm: each rank reduces its cells to one 8-double record.  Record and both strips travel in ONE
+all-gather of ~1 KB per rank and attempt (pure latency; one collective instead of a batch of neighbour
+sends/receives plus an all-gather); every rank reads its neighbours' strips out of the gathered buffer and
+combines the records IN RANK ORDER, so all ranks take bit-identical accept/reject decisions.  No host synchronisation inside the loop: kernels and collectives are enqueued on one stream, the
 controller state lives on the device, and the host only polls the status every ``poll`` attempts.
 
 The arithmetic is behind a small engine interface so that the driver logic is testable on CPU (gloo) with a
@@ -46,6 +46,7 @@ class HipSlabEngine:
         blk.shallow_limit = float(pde_parms["ShallowLimit"]) / float(pde_parms["Xstar"])
         blk.deep_limit = float(pde_parms["DeepLimit"]) / float(pde_parms["Xstar"])
         blk.FV_switch = int(pde_parms["FV_switch"])
+        blk.dPhi_variable = int(bool(pde_parms.get("dPhi_variable", False)))
         rc = self.lib.marl_ctx_create_slab(C.byref(blk), N_global, begin, end, halo, device, C.byref(self.ctx))
         if rc != 0:
             self.ctx = C.c_void_p()
@@ -128,36 +129,27 @@ class DomainDecomposedRK45:
         self.engine = engine_factory(self.begin, self.end)
         e = self.engine
         n = STRIP * halo
-        self.send_lo, self.send_hi = e.new_tensor(n), e.new_tensor(n)
-        self.recv_lo, self.recv_hi = e.new_tensor(n), e.new_tensor(n)
-        self.rec = e.new_tensor(8)
+        # One message per rank and attempt: [record (8) | lower strip (n) | upper strip (n)].  A single all-gather moves
+        # the halos AND the step-control records (P x ~1 KB: pure latency either way, and one collective instead of a
+        # batch of sends/receives plus an all-gather); every rank then reads its two neighbours' strips in place.
+        self.msg = 8 + 2 * n
+        self.send = e.new_tensor(self.msg)
+        self.rec, self.send_lo, self.send_hi = self.send[:8], self.send[8:8 + n], self.send[8 + n:]
+        self.gathered = e.new_tensor(self.msg * self.world).view(self.world, self.msg)
+        lo_src = self.gathered[self.rank - 1] if self.rank > 0 else self.send                 # lower neighbour's UPPER strip
+        hi_src = self.gathered[self.rank + 1] if self.rank < self.world - 1 else self.send    # upper neighbour's LOWER strip
+        self.recv_lo, self.recv_hi = lo_src[8 + n:], hi_src[8:8 + n]
         self.recs = e.new_tensor(8 * self.world)
 
     # -- communication ---------------------------------------------------------------------------
-    def _exchange(self):
-        """send_lo -> lower neighbour's recv_hi, send_hi -> upper neighbour's recv_lo (paired P2P ops)."""
-        if self.world == 1:
-            return
-        dist = self.dist
-        ops = []
-        if self.rank > 0:
-            ops += [dist.P2POp(dist.isend, self.send_lo, self.rank - 1, self.group),
-                    dist.P2POp(dist.irecv, self.recv_lo, self.rank - 1, self.group)]
-        if self.rank < self.world - 1:
-            ops += [dist.P2POp(dist.isend, self.send_hi, self.rank + 1, self.group),
-                    dist.P2POp(dist.irecv, self.recv_hi, self.rank + 1, self.group)]
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-
-    def _gather_records(self):
+    def _exchange(self, which):
+        """pack -> all-gather -> unpack; afterwards ``recs`` holds every rank's record in rank order."""
+        self.engine.pack(which, self.send_lo, self.send_hi)
         if self.world == 1:
             self.recs.copy_(self.rec)
-        else:
-            self.dist.all_gather_into_tensor(self.recs, self.rec, group=self.group)
-
-    def _halo_round(self, which):
-        self.engine.pack(which, self.send_lo, self.send_hi)
-        self._exchange()
+            return
+        self.dist.all_gather_into_tensor(self.gathered.view(-1), self.send, group=self.group)
+        self.recs.view(self.world, 8).copy_(self.gathered[:, :8])
         self.engine.unpack(which, self.recv_lo, self.recv_hi)
 
     # -- the integration ---------------------------------------------------------------------------
@@ -166,18 +158,16 @@ class DomainDecomposedRK45:
         Returns the marl_stats of the run (identical on every rank)."""
         e = self.engine
         e.load(y_owned)
-        self._halo_round(0)          # y halos
+        self._exchange(0)            # y halos
         e.rhs0()
-        self._halo_round(0)          # f halos (FSAL vector)
         e.monitors(self.rec)
-        self._gather_records()
+        self._exchange(0)            # f halos (FSAL vector) + the monitors record of y(t0)
         e.init_control(self.recs, self.world, float(t_span[0]), float(t_span[1]), float(first_step), float(rtol),
                        float(atol), int(max_attempts))
         while True:
             for _ in range(self.poll):
                 e.attempt(self.rec)
-                self._halo_round(-1)
-                self._gather_records()
+                self._exchange(-1)
                 e.control(self.recs, self.world)
             st = e.status()
             if st.status != 1:

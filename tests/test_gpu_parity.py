@@ -413,11 +413,12 @@ def _run_slabs(torch, p, N, P, y0, t1, h0, rtol, atol, max_attempts=0):
     return stats, got
 
 
-def test_domain_decomposition_slabs_on_one_gpu(torch_cuda, oracle):
+@pytest.mark.parametrize("vd", [False, True])
+def test_domain_decomposition_slabs_on_one_gpu(torch_cuda, oracle, vd):
     """BASELINE config 5 logic on ONE GPU: checks the slab kernels (pack / unpack / halo-consuming fused attempt /
-    shared control) against the oracle's single-grid run, incl. rejected attempts."""
+    shared control) against the oracle's single-grid run, incl. rejected attempts (and with the dPhi_variable kernels)."""
     N, P = 5000, 3
-    p = scenario("A", N)
+    p = scenario("A", N) | {"dPhi_variable": vd}
     y0 = synthetic_state(p, N, amplitude=0.05)
     dx2 = ((p["max_depth"] / p["Xstar"]) / N) ** 2
     t1, h0, rtol, atol = 40 * dx2, 0.5 * dx2, 1e-5, 1e-7
