@@ -337,7 +337,7 @@ static void record_to_events(const double* r, double* g)
 struct Rk4Variant { int blk, cpt, nsteps; };
 static const Rk4Variant kRk4Variants[] = {
     {256, 1, 1}, {256, 1, 2}, {256, 2, 1}, {256, 2, 2}, {128, 1, 4}, {128, 1, 8}, {256, 2, 4}, {512, 1, 1}, {256, 4, 1}, {128, 1, 1},
-    {256, 1, 4}, {256, 1, 8},
+    {256, 1, 4}, {256, 1, 8}, {256, 1, 16},
 };
 constexpr int kNumRk4Variants = sizeof(kRk4Variants) / sizeof(kRk4Variants[0]);
 
@@ -358,15 +358,17 @@ static void launch_rk4_t(marl_ctx* ctx, const double* yin, double* yout, int lay
 constexpr int kVdRk4Variant = 10;   // {256, 1, 4}
 constexpr int kVdRk45Variant = 0;   // {256, 1}
 
-static int launch_rk4(marl_ctx* ctx, int v, bool single, const double* yin, double* yout, int layout, double dt)
+// nsteps: steps fused in this launch - the variant's own depth, or a smaller instantiated one for the remainder
+static int launch_rk4(marl_ctx* ctx, int v, int nsteps, const double* yin, double* yout, int layout, double dt)
 {
     const Rk4Variant& rv = kRk4Variants[v];
-    const int key = rv.blk * 1000 + rv.cpt * 100 + (single ? 1 : rv.nsteps);
+    const int key = rv.blk * 1000 + rv.cpt * 100 + nsteps;
     switch (key) {
         case 256101: if (ctx->var_dphi) launch_rk4_t<256, 1, 1, true>(ctx, yin, yout, layout, dt); else launch_rk4_t<256, 1, 1>(ctx, yin, yout, layout, dt); break;
         case 256102: launch_rk4_t<256, 1, 2>(ctx, yin, yout, layout, dt); break;
         case 256104: if (ctx->var_dphi) launch_rk4_t<256, 1, 4, true>(ctx, yin, yout, layout, dt); else launch_rk4_t<256, 1, 4>(ctx, yin, yout, layout, dt); break;
         case 256108: launch_rk4_t<256, 1, 8>(ctx, yin, yout, layout, dt); break;
+        case 256116: launch_rk4_t<256, 1, 16>(ctx, yin, yout, layout, dt); break;
         case 256201: launch_rk4_t<256, 2, 1>(ctx, yin, yout, layout, dt); break;
         case 256202: launch_rk4_t<256, 2, 2>(ctx, yin, yout, layout, dt); break;
         case 256204: launch_rk4_t<256, 2, 4>(ctx, yin, yout, layout, dt); break;
@@ -386,7 +388,9 @@ static int default_rk4_variant(const marl_ctx* ctx)
     if (ctx->var_dphi) return kVdRk4Variant;
     if (ctx->rk4_variant >= 0 && ctx->rk4_variant < kNumRk4Variants) return (int)ctx->rk4_variant;
     const int64_t n = ctx->slab.out_hi - ctx->slab.out_lo;
-    return n <= 262144 ? 11 : 10;  // 256-thread blocks; 8 steps per launch while the launch boundary matters, 4 beyond (tools/variant_sweep.sh)
+    // 256-thread blocks; the smaller the grid, the more the launch boundary matters against the recomputed halo:
+    // 16 / 8 / 4 steps per launch (tools/variant_sweep.sh)
+    return n <= 98304 ? 12 : (n <= 262144 ? 11 : 10);
 }
 
 // y (device, `layout`) advanced in place; `tmp` is a second buffer of the same size
@@ -398,14 +402,20 @@ static int rk4_run(marl_ctx* ctx, double* y, double* tmp, int layout, double dt,
     double* b = tmp;
     int64_t left = nsteps;
     while (left >= per) {
-        if (int rc = launch_rk4(ctx, v, false, a, b, layout, dt)) return rc;
+        if (int rc = launch_rk4(ctx, v, per, a, b, layout, dt)) return rc;
         std::swap(a, b);
         left -= per;
     }
-    while (left > 0) {
-        if (int rc = launch_rk4(ctx, v, true, a, b, layout, dt)) return rc;
-        std::swap(a, b);
-        left--;
+    // remainder: the {256, 1, *} family is instantiated at every power of two below its depth; others step singly
+    const bool family = kRk4Variants[v].blk == 256 && kRk4Variants[v].cpt == 1 && !ctx->var_dphi;
+    for (int chunk = per / 2; chunk >= 1 && left > 0; chunk /= 2) {
+        const int c = family ? chunk : 1;
+        while (left >= c) {
+            if (int rc = launch_rk4(ctx, v, c, a, b, layout, dt)) return rc;
+            std::swap(a, b);
+            left -= c;
+            if (family) break;   // at most one launch per power of two
+        }
     }
     if (a != y) HIP_OK(ctx, hipMemcpyAsync(y, a, sizeof(double) * state_doubles(ctx->slab.n_buf, layout), hipMemcpyDeviceToDevice, ctx->stream));
     return 0;

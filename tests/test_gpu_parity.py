@@ -106,7 +106,7 @@ def test_rhs_device_layouts_against_oracle(torch_cuda, oracle, N):
 
 
 @pytest.mark.parametrize("layout", [0, 1])
-@pytest.mark.parametrize("variant", range(12))
+@pytest.mark.parametrize("variant", range(13))
 def test_rk4_fused_variants_against_oracle(torch_cuda, oracle, variant, layout):
     """Every fused-RK4 instantiation (block size, cells/thread, steps/launch) on a grid that is not a
     multiple of any tile, incl. a step count that is not a multiple of the fused depth."""
