@@ -21,12 +21,14 @@ N = 1 << 20
 def counter_table(sub):
     """kernel -> counter -> (sum, dispatches)"""
     files = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)
-    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0, 0.0]))   # sum, dispatches, max
     for f in files:
         for row in csv.DictReader(open(f)):
             a = acc[row["Kernel_Name"]][row["Counter_Name"]]
-            a[0] += float(row["Counter_Value"])
+            v = float(row["Counter_Value"])
+            a[0] += v
             a[1] += 1
+            a[2] = max(a[2], v)
     return acc
 
 
@@ -36,14 +38,15 @@ tables = {c: counter_table("pmc_" + c) for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ
 cal = None
 for k, v in tables["FETCH_SIZE"].items():
     if "convert_kernel<0, 1>" in k:
-        cal = (5 * 8 * N / 1024.0) / (v["FETCH_SIZE"][0] / v["FETCH_SIZE"][1])
+        cal = (5 * 8 * N / 1024.0) / v["FETCH_SIZE"][2]   # the N = 2^20 dispatch (the default bench also converts a small grid)
 out["fetch_calibration_factor"] = cal
 for k in tables["FETCH_SIZE"]:
     if "marl::" not in k or not ("rk4_fused" in k or "convert_kernel<0, 1>" in k):
         continue
     f = tables["FETCH_SIZE"][k]["FETCH_SIZE"]
     w = tables["WRITE_SIZE"][k]["WRITE_SIZE"]
-    e = {"FETCH_SIZE_KiB": f[0] / f[1], "WRITE_SIZE_KiB": w[0] / w[1], "dispatches": f[1]}
+    conv = "convert_kernel" in k
+    e = {"FETCH_SIZE_KiB": f[2] if conv else f[0] / f[1], "WRITE_SIZE_KiB": w[2] if conv else w[0] / w[1], "dispatches": f[1]}
     e["hbm_read_bytes_per_launch"] = e["FETCH_SIZE_KiB"] * 1024 * (cal or 2.0)
     e["hbm_write_bytes_per_launch"] = e["WRITE_SIZE_KiB"] * 1024
     e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
@@ -51,7 +54,7 @@ for k in tables["FETCH_SIZE"]:
         e["algorithmic_bytes_per_launch"] = 80 * N * 4
         sq = {}
         for t in ("SQ1", "SQ2"):
-            for c, (s, n) in tables[t].get(k, {}).items():
+            for c, (s, n, _) in tables[t].get(k, {}).items():
                 sq[c] = s / n
         if sq:
             waves = sq.get("SQ_WAVES", 0)
