@@ -1,14 +1,25 @@
 #!/usr/bin/env python3
 """Throughput of the hot path on MI355X: grid-point-steps/s of the fused five-field RK integrators.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload rk4_single|sweep_rk45|rk45_single] ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload rk4_single|sweep_rk45|rk45_single|dd_rk45] ...
 
 Default (N=1): BASELINE.json's headline - ONE grid of 2^20 depth cells, fixed-step classical RK4, fp64,
 fused HIP stencil (configs[1] at the size the north_star quotes its target on).  A "step" is one RK4
-step of the whole grid.  With --gpus N each rank integrates its own independent grid of the same size
-(weak scaling, no data-path collective - a sweep over independent high-resolution columns).
-`--workload sweep_rk45` is BASELINE config 3/4: 4096 instances x 1024 cells per GPU, adaptive RK45 with
-per-instance controllers, a "step" being one attempted step of every instance.
+step of the whole grid.
+
+--gpus N: one process per GPU.  Under `torch.distributed.run` (WORLD_SIZE set) this process IS one rank;
+started directly (`python bench.py --gpus N`) it starts the N rank processes itself BEFORE anything touches
+the GPU and waits for them.  Rank r binds cuda:LOCAL_RANK and joins an RCCL ("nccl") process group.  The
+headline line is the same workload on every rank (each rank integrates its own grid: weak scaling, no
+data-path collective); BASELINE configs[2]/[3] (the batched sweep, 4096 instances per GPU, no collective) and
+configs[4] (ONE grid of 2^22 cells domain-decomposed over all ranks, RCCL all-gather per attempt) are timed
+afterwards and reported under `extra`, best effort and under a deadline (a failure or hang there cannot take
+the headline line with it).
+
+Timing: W untimed warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier +
+torch.cuda.synchronize() on both sides; the block is repeated until >= 50 ms have been timed and the MEDIAN
+block (max over ranks per block) is reported (`reps`), so that a small K measures the kernel and not one
+launch/synchronise round trip.
 
 One JSON line is printed by rank 0 (contract in the task description); `roofline` is for the dominant
 kernel with HIP-event timing on the launch stream, `cpu_baseline` is the oracle (a C port of the
@@ -16,11 +27,13 @@ reference's serial loop) timed on this host on a bounded sample of the same work
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -28,10 +41,57 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 BYTES_PER_POINT_STEP = 80.0    # 5 fields x 8 B read + 5 x 8 B written per grid-point-step
+MIN_TIMED_S = 0.05             # repeat the K-step block until this much has been timed
+MAX_REPS = 400
+EXTRAS_DEADLINE_S = float(os.environ.get("MARL_BENCH_EXTRAS_DEADLINE", "240"))
 
 
-def synthetic(p, N, batch=None):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="rk4_single", choices=["rk4_single", "sweep_rk45", "sweep_rk4", "rk45_single", "dd_rk45"])
+    ap.add_argument("--n", type=int, default=None, help="cells per grid (default 2^20 single, 1024 sweep, 2^22 dd)")
+    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU for the sweep workloads")
+    ap.add_argument("--layout", type=int, default=1, help="device layout of single-grid runs: 0 field-major, 1 tiled")
+    ap.add_argument("--variant", type=int, default=-1, help="kernel variant (see DESIGN.md); -1 = default")
+    ap.add_argument("--no-reuse", action="store_true", help="rk4_single: every evaluation takes the full transcendental path")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline workload only")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes (this parent never touches the GPU)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            for p in procs:
+                if p.poll() not in (None, 0):   # one rank failed: the others would wait in a collective for ever
+                    rc = p.returncode
+                    for q in procs:
+                        if q.poll() is None:
+                            q.terminate()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc or max((p.returncode or 0) for p in procs)
+
+
+def synthetic(p, N):
     """SURVEY.md 8d synthetic input: initial values x (1 + 0.01 sin(2 pi 8 x / L)); no RNG."""
+    import numpy as np
     L = p["max_depth"] / p["Xstar"]
     x = (np.arange(N) + 0.5) * (L / N)
     y = np.stack([np.full(N, p[k]) for k in ("CAIni", "CCIni", "cCaIni", "cCO3Ini", "PhiIni")])
@@ -39,27 +99,24 @@ def synthetic(p, N, batch=None):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None)
-    ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="rk4_single", choices=["rk4_single", "sweep_rk45", "sweep_rk4", "rk45_single", "dd_rk45"])
-    ap.add_argument("--n", type=int, default=None, help="cells per grid (default 2^20 single, 1024 sweep)")
-    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU for the sweep workloads")
-    ap.add_argument("--layout", type=int, default=1, help="device layout of single-grid runs: 0 field-major, 1 tiled")
-    ap.add_argument("--variant", type=int, default=-1, help="kernel variant (see DESIGN.md); -1 = default")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--extras", action="store_true", help="also time BASELINE configs 2 and 3 and add them under `extra`")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; "
+                 "run `python bench.py --gpus N` (it starts the ranks itself) or torchrun --nproc-per-node N ... --gpus N")
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL / tensor sharing)
+    import numpy as np
     import torch
     import torch.distributed as dist
     from dataclasses import asdict
     from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
     from marlpde_amd.parameters import Map_Scenario
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the package has no CPU path)"
@@ -67,59 +124,77 @@ def main():
     if os.environ.get("MARL_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        backend = os.environ.get("MARL_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+    use_dist = world > 1 or os.environ.get("MARL_BENCH_FORCE_DIST") == "1"   # FORCE_DIST: one-rank RCCL group (init + collectives run)
+    backend = os.environ.get("MARL_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     stream = torch.cuda.current_stream()
+    red_dev = "cuda" if (not use_dist or backend == "nccl") else "cpu"
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(values):
+        t = torch.tensor(values, dtype=torch.float64, device=red_dev)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
+
     base = asdict(Map_Scenario())
-    single = args.workload in ("rk4_single", "rk45_single", "dd_rk45")
-    N = args.n or ((1 << 20) if single else 1024)
-    steps = args.steps if args.steps is not None else (4000 if single else 2000)
-    warmup = args.warmup if args.warmup is not None else (200 if single else 20)   # ~6 ms: lets the clocks settle
 
-    def timed(fn_warm, fn_timed):
-        """warm-up, then the timed region bracketed by barrier + synchronize; returns (wall s, event ms)."""
+    def timed(fn_warm, fn_block, repeat=True):
+        """Warm-up, then blocks of the timed region (fn_block enqueues EXACTLY K steps), each bracketed by barrier +
+        synchronize on both sides.  Returns (median over blocks of the max-over-ranks wall time [s], median HIP-event
+        time of this rank's blocks [ms], number of blocks)."""
         fn_warm()
-        barrier()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record(stream)
-        fn_timed()
-        e1.record(stream)
-        barrier()
-        wall = time.perf_counter() - t0
-        return wall, e0.elapsed_time(e1)
 
-    def run_rk4_single(N, steps, warmup, layout, variant):
+        def one():
+            barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record(stream)
+            fn_block()
+            e1.record(stream)
+            barrier()
+            return time.perf_counter() - t0, e0.elapsed_time(e1)
+        first = one()
+        t_first = max_over_ranks([first[0]])[0]            # the same number of blocks on every rank
+        reps = min(MAX_REPS, max(1, math.ceil(MIN_TIMED_S / max(t_first, 1e-7)))) if repeat else 1
+        blocks = [first] + [one() for _ in range(reps - 1)]
+        walls = max_over_ranks([b[0] for b in blocks])
+        return float(np.median(walls)), float(np.median([b[1] for b in blocks])), reps
+
+    # ---- workloads ------------------------------------------------------------------------------------------
+    def run_rk4_single(N, steps, warmup, layout, variant, no_reuse=False):
         p = base | {"N": N}
         eq = LMAHeureuxPorosityDiff.from_scenario(p, device=local_rank)
         eq.use_stream(stream.cuda_stream)
         if variant >= 0:
             eq.set_option("rk4_variant", variant)
+        if no_reuse:
+            eq.set_option("no_reuse", 1)
         y0 = torch.from_numpy(synthetic(p, N)).cuda()
         buf = torch.zeros(eq.state_doubles(layout), dtype=torch.float64, device="cuda")
         eq.convert_layout_device(y0.data_ptr(), buf.data_ptr(), 0, layout)
         dt = 0.25 * (eq.Depths.length / N) ** 2
         # untimed settle phase (~60 ms of the same kernel): the chip's clocks ramp for tens of ms after idle, and a short
-        # --steps run would otherwise measure the ramp; then the W warm-up steps, then the K timed steps
+        # --steps run would otherwise measure the ramp; then the W warm-up steps, then the blocks of K timed steps
         eq.integrate_rk4_device(buf.data_ptr(), dt, 2000, layout)
-        wall, ev_ms = timed(lambda: eq.integrate_rk4_device(buf.data_ptr(), dt, warmup, layout),
-                            lambda: eq.integrate_rk4_device(buf.data_ptr(), dt, steps, layout))
+        wall, ev_ms, reps = timed(lambda: eq.integrate_rk4_device(buf.data_ptr(), dt, warmup, layout),
+                                  lambda: eq.integrate_rk4_device(buf.data_ptr(), dt, steps, layout))
         assert bool(torch.isfinite(buf).all()), "state went non-finite"
         eq.close()
-        return wall, ev_ms, dt
+        return wall, ev_ms, reps
 
-    def run_sweep(N, B, steps, warmup, adaptive):
+    def run_sweep(N, B, steps, warmup, adaptive, variant=-1):
         # 16x16x16-style grid over the three knobs the reference's tests vary (SURVEY.md 8d), B instances per GPU
         k = max(1, round(B ** (1 / 3)))
         idx = np.arange(B) + rank * B
@@ -133,8 +208,8 @@ def main():
         p = base | {"N": N}
         eq = LMAHeureuxPorosityDiff.from_scenario(p, device=local_rank, instances=inst)
         eq.use_stream(stream.cuda_stream)
-        if args.variant >= 0:
-            eq.set_option("sweep_variant", args.variant)
+        if variant >= 0:
+            eq.set_option("sweep_variant", variant)
         y0 = torch.from_numpy(np.stack([synthetic(p | d, N) for d in inst])).cuda()
         dx2 = (eq.Depths.length / N) ** 2
         stats = {}
@@ -145,7 +220,7 @@ def main():
             else:
                 eq.sweep_rk4_device(buf.data_ptr(), 0.25 * dx2, n)
         warm, buf = y0.clone(), y0.clone()
-        wall, ev_ms = timed(lambda: go(warmup, warm), lambda: go(steps, buf))
+        wall, ev_ms, reps = timed(lambda: go(warmup, warm), lambda: go(steps, buf), repeat=False)
         assert bool(torch.isfinite(buf).all()), "state went non-finite"
         info = {}
         if adaptive:
@@ -154,14 +229,14 @@ def main():
             assert np.all(acc + rej == steps), "every instance must have spent its attempt budget"
             info = {"accepted_steps_mean": float(acc.mean()), "rejected_steps_mean": float(rej.mean())}
         eq.close()
-        return wall, ev_ms, info
+        return wall, ev_ms, reps, info
 
-    def run_rk45_single(N, steps, warmup, layout):
+    def run_rk45_single(N, steps, warmup, layout, variant=-1):
         p = base | {"N": N}
         eq = LMAHeureuxPorosityDiff.from_scenario(p, device=local_rank)
         eq.use_stream(stream.cuda_stream)
-        if args.variant >= 0:
-            eq.set_option("rk45_variant", args.variant)
+        if variant >= 0:
+            eq.set_option("rk45_variant", variant)
         y0 = torch.from_numpy(synthetic(p, N)).cuda()
         dx2 = (eq.Depths.length / N) ** 2
         out = {}
@@ -173,13 +248,14 @@ def main():
             b = torch.zeros(eq.state_doubles(layout), dtype=torch.float64, device="cuda")
             eq.convert_layout_device(y0.data_ptr(), b.data_ptr(), 0, layout)
             bufs.append(b)
-        wall, ev_ms = timed(lambda: go(warmup, bufs[0]), lambda: go(steps, bufs[1]))
+        wall, ev_ms, reps = timed(lambda: go(warmup, bufs[0]), lambda: go(steps, bufs[1]), repeat=False)
         r = out["res"]
         eq.close()
-        return wall, ev_ms, {"accepted_steps": r.n_accepted, "rejected_steps": r.n_rejected}
+        return wall, ev_ms, reps, {"accepted_steps": r.n_accepted, "rejected_steps": r.n_rejected}
 
     def run_dd(N, steps, warmup):
-        """BASELINE config 5: ONE grid of N cells split over all ranks, RCCL halo exchange + all-gathered control."""
+        """BASELINE configs[4]: ONE grid of N cells split over all ranks, halo strips + step-control records in one
+        all-gather per attempt (RCCL)."""
         from marlpde_amd.domain import DomainDecomposedRK45, owned_slice
         p = base | {"N": N}
         dd = DomainDecomposedRK45(p, N, device=local_rank)
@@ -191,59 +267,48 @@ def main():
         def go(n):
             y = torch.from_numpy(own.copy()).cuda()
             out["st"] = dd.integrate(y, (0.0, 1.0e9), 0.5 * dx2, 1e-3, 1e-3, max_attempts=n)
-        wall, ev_ms = timed(lambda: go(warmup), lambda: go(steps))
+        wall, ev_ms, reps = timed(lambda: go(warmup), lambda: go(steps), repeat=False)
         st = out["st"]
+        info = {"accepted_steps": int(st.n_accepted), "rejected_steps": int(st.n_rejected), "transport": dd.transport}
         dd.close()
-        return wall, ev_ms, {"accepted_steps": int(st.n_accepted), "rejected_steps": int(st.n_rejected)}
+        return wall, ev_ms, reps, info
 
+    # ---- headline -------------------------------------------------------------------------------------------
+    single = args.workload in ("rk4_single", "rk45_single", "dd_rk45")
+    N = args.n or ((1 << 22) if args.workload == "dd_rk45" else (1 << 20) if single else 1024)
+    defaults = {"rk4_single": (4000, 200), "rk45_single": (2000, 20), "sweep_rk45": (2000, 20), "sweep_rk4": (2000, 20), "dd_rk45": (500, 16)}
+    steps = args.steps if args.steps is not None else defaults[args.workload][0]
+    warmup = args.warmup if args.warmup is not None else defaults[args.workload][1]
     extra = {}
     if args.workload == "dd_rk45":
-        N = args.n or (1 << 22)
-        steps = args.steps if args.steps is not None else 500
-        warmup = args.warmup if args.warmup is not None else 16
-        wall, ev_ms, info = run_dd(N, steps, warmup)
+        wall, ev_ms, reps, info = run_dd(N, steps, warmup)
         units = float(N) * steps / world       # per-rank share; `value` multiplies by world below
         workload = f"dd_rk45 ONE grid N={N} over {world} rank(s), halo exchange + all-gathered step control (BASELINE configs[4])"
-        kernel = "rk45_attempt_kernel"
+        kernel, parallelism, scaling = "rk45_attempt_kernel", f"1-D domain decomposition over {world} rank(s); one all-gather (halo strips + step-control record) per attempted step", "strong"
         extra.update(info)
     elif args.workload == "rk4_single":
-        wall, ev_ms, dt = run_rk4_single(N, steps, warmup, args.layout, args.variant)
+        wall, ev_ms, reps = run_rk4_single(N, steps, warmup, args.layout, args.variant, args.no_reuse)
         units = float(N) * steps
-        workload = f"rk4_fused_single_grid N={N} fp64 (north_star target size 2^20; BASELINE configs[1] is the same kernel at N=65536, reported under extra), dt=0.25dx^2"
-        kernel = "rk4_fused_kernel"
+        workload = (f"rk4_fused_single_grid N={N} fp64 (north_star target size 2^20; BASELINE configs[1] is the same kernel at "
+                    f"N=65536, reported under extra), dt=0.25dx^2" + (", transcendental reuse disabled" if args.no_reuse else ""))
+        kernel, parallelism, scaling = "rk4_fused_kernel", f"{world} rank(s), each integrating its own grid; no collective in the data path", "weak"
     elif args.workload in ("sweep_rk45", "sweep_rk4"):
-        wall, ev_ms, info = run_sweep(N, args.batch, steps, warmup, args.workload == "sweep_rk45")
+        wall, ev_ms, reps, info = run_sweep(N, args.batch, steps, warmup, args.workload == "sweep_rk45", args.variant)
         units = float(N) * args.batch * steps
         workload = (f"{args.workload} batch={args.batch} instances/GPU x N={N}, one workgroup per instance "
                     f"(BASELINE configs[2]/[3]); steps = attempted steps")
         kernel = "rk45_sweep_kernel" if args.workload == "sweep_rk45" else "rk4_sweep_kernel"
+        parallelism, scaling = f"instances sharded over {world} rank(s); no collective in the data path", "weak"
         extra.update(info)
     else:
-        wall, ev_ms, info = run_rk45_single(N, steps, warmup, args.layout)
+        wall, ev_ms, reps, info = run_rk45_single(N, steps, warmup, args.layout, args.variant)
         units = float(N) * steps
         workload = f"rk45_fused_single_grid N={N} fp64, rtol=atol=1e-3; steps = attempted steps"
-        kernel = "rk45_attempt_kernel"
+        kernel, parallelism, scaling = "rk45_attempt_kernel", f"{world} rank(s), each integrating its own grid; no collective in the data path", "weak"
         extra.update(info)
+    value = units * world / wall
 
-    # max over ranks of the wall time of the timed region
-    wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda" if (world == 1 or dist.get_backend() == "nccl") else "cpu")
-    if world > 1:
-        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
-    wall_max = float(wall_t.item())
-    value = units * world / wall_max
-
-    # BASELINE.json configs[1] (N = 65 536, fused RK4) next to the north_star headline size: 4000 steps, ~15 ms
-    if rank == 0 and world == 1 and args.workload == "rk4_single" and args.n is None and args.variant < 0:
-        w2, _, _ = run_rk4_single(65536, 4000, 200, args.layout, -1)
-        extra["BASELINE_configs1_rk4_N65536"] = {"value": 65536.0 * 4000 / w2, "unit": "grid-point-steps/s",
-                                                 "frac_of_hbm_roofline": BYTES_PER_POINT_STEP * 65536.0 * 4000 / w2 / 1e9 / HBM_PEAK_GBS}
-    if rank == 0 and args.extras and world == 1:
-        w2, e2, _ = run_rk4_single(65536, 10000, 16, args.layout, -1)
-        extra["config2_rk4_N65536_gps"] = 65536.0 * 10000 / w2
-        w3, e3, info3 = run_sweep(1024, 4096, 2000, 20, True)
-        extra["config3_sweep_rk45_4096x1024_gps"] = 1024.0 * 4096 * 2000 / w3
-        extra["config3_info"] = info3
-
+    # ---- CPU baseline (rank 0 only; the oracle is the checker / baseline, never the product) -----------------
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import oracle as orc
@@ -251,7 +316,7 @@ def main():
         ncores = min(len(os.sched_getaffinity(0)), 16)  # a 1-GPU box shares its host: 16 CPUs per GPU
         L = base["max_depth"] / base["Xstar"]
         if args.workload == "rk4_single":
-            Nc, sc = N, (2 if N >= (1 << 19) else max(2, int(2e6 // N)))
+            Nc, sc = N, (12 if N >= (1 << 19) else max(2, int(1.2e7 // N)))   # ~3 s single-thread + ~3 s all cores
             P = orc.params_from_dict(base | {"N": Nc})
             yc = synthetic(base | {"N": Nc}, Nc)
             dtc = 0.25 * (L / Nc) ** 2
@@ -264,7 +329,7 @@ def main():
                    "sample_all_cores": f"same, OpenMP over cells, {4 * sc} steps, {ncores} threads"}
         elif single:
             Nc = min(N, 1 << 20)
-            sc = max(3, int(4e6 // Nc))
+            sc = max(3, int(1.2e7 // Nc))
             P = orc.params_from_dict(base | {"N": Nc})
             t0 = time.perf_counter()
             orc.rk45(P, Nc, synthetic(base | {"N": Nc}, Nc), 0.0, 1e9, 0.5 * (L / Nc) ** 2, 1e-3, 1e-3, max_attempts=sc, max_steps_out=1)
@@ -272,7 +337,7 @@ def main():
             cpu = {"value": Nc * sc / t1c, "unit": "grid-point-steps/s", "cores": 1, "kind": "port",
                    "sample": f"oracle RK45 (C port, scipy-exact controller), N={Nc}, {sc} attempted steps, 1 thread"}
         else:
-            Bc, sc = 16, 200
+            Bc, sc = 16, 600
             inst = [{"Phi0": 0.5 + 0.3 * i / 15, "PhiIni": 0.5 + 0.3 * ((i * 7) % 16) / 15} for i in range(Bc)]
             t0 = time.perf_counter()
             for d in inst:
@@ -284,38 +349,110 @@ def main():
             cpu = {"value": N * Bc * sc / t1c, "unit": "grid-point-steps/s", "cores": 1, "kind": "port",
                    "sample": f"oracle RK45 (C port, scipy-exact controller), {Bc} instances x N={N} x {sc} attempts, 1 thread"}
 
+    # ---- roofline of the dominant kernel ---------------------------------------------------------------------
+    line = None
     if rank == 0:
-        # dominant kernel: algorithmic bytes per launch / average launch duration (HIP events around the timed
-        # region on the launch stream; launches are back to back, so gaps count against the kernel)
-        per_launch = {"rk4_single": 4 if (N > 262144 and args.variant < 0) else None}.get(args.workload)
+        # achieved = ALGORITHMIC bytes per launch / average launch duration = 80 B x grid-point-steps / HIP-event time
+        # of the timed block on the launch stream (launches are back to back, so gaps count against the kernel)
         achieved = BYTES_PER_POINT_STEP * units / (ev_ms * 1e-3) / 1e9  # GB/s
-        traffic, traffic_note = None, "no PMC summary committed for this kernel variant"
-        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-        if per_launch and args.workload == "rk4_single" and N == (1 << 20) and os.path.exists(pmc_file):
-            k = next((v for n, v in json.load(open(pmc_file))["kernels"].items() if "rk4_fused_kernel<256, 1, 1, 4" in n), None)
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "kernel": kernel, "algorithmic_bytes_per_grid_point_step": BYTES_PER_POINT_STEP,
+                "limiter": "fp64 VALU issue (the kernel advances several steps per pass over the state: measured HBM traffic is a "
+                           "fraction of the algorithmic bytes; see hbm_measured_gbs and DESIGN.md 5)",
+                "note": "achieved = algorithmic bytes (80 B x grid-point-steps of one launch) / launch duration (HIP events on the launch "
+                        "stream); it is an effective rate against the one-step-per-pass HBM roofline, NOT the HBM bandwidth the "
+                        "kernel draws - that is hbm_measured_gbs (PMC bytes per launch / launch duration)"}
+        pmc = None
+        for tag in ("r02", "r01"):
+            f = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.json")
+            if os.path.exists(f):
+                pmc = (tag, json.load(open(f)))
+                break
+        if pmc and args.workload == "rk4_single" and N == (1 << 20) and args.variant < 0:
+            k = next((v for n, v in pmc[1]["kernels"].items() if "rk4_fused_kernel<256, 1, 1, 4" in n), None)
             if k:
-                traffic = k["hbm_bytes_per_launch"]
-                traffic_note = ("HBM bytes per launch (4 RK4 steps) from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
-                                "FETCH_SIZE doubled per the gfx950 calibration (profiles/r01_pmc_hbm_traffic.json); "
-                                f"algorithmic bytes per launch = {k['algorithmic_bytes_per_launch']}")
+                launches = steps / 4.0
+                roof["traffic"] = k["hbm_bytes_per_launch"]
+                roof["hbm_measured_gbs"] = k["hbm_bytes_per_launch"] * launches / (ev_ms * 1e-3) / 1e9
+                roof["hbm_measured_frac_of_peak"] = roof["hbm_measured_gbs"] / HBM_PEAK_GBS
+                roof["traffic_note"] = ("HBM bytes per launch (4 RK4 steps) from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                                        f"FETCH_SIZE doubled per the gfx950 calibration (profiles/{pmc[0]}_pmc_hbm_traffic.json, collected with "
+                                        f"tools/profile_round.sh, not in this run); algorithmic bytes per launch = {k['algorithmic_bytes_per_launch']}")
         line = {
             "metric": "grid-point-steps/sec (5 fields, fp64)", "value": value, "unit": "grid-point-steps/s",
-            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * wall_max / steps,
-            "higher_is_better": True, "scaling": "strong" if args.workload == "dd_rk45" else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * wall / steps, "reps": reps,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "N": N, "instances_per_gpu": (1 if single else args.batch),
                        "layout": ("tiled" if args.layout else "field-major") if single else "field-major",
-                       "parallelism": f"{world} independent rank(s), no collectives in the data path"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note, "kernel": kernel,
-                         "algorithmic_bytes_per_grid_point_step": BYTES_PER_POINT_STEP,
-                         "note": "achieved = 80 B x grid-point-steps / HIP-event time; the kernel is fp64-VALU-bound, see DESIGN.md"},
-            "cpu_baseline": cpu,
+                       "parallelism": parallelism,
+                       "timing": f"median of {reps} block(s) of {steps} steps, each bracketed by barrier + synchronize; max over ranks per block"},
+            "roofline": roof, "cpu_baseline": cpu,
         }
-        if extra:
-            line["extra"] = extra
-        print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+
+    # ---- extras: the other BASELINE configs, best effort under a deadline -----------------------------------
+    printed = threading.Lock()
+
+    def emit(timed_out=False):
+        if not printed.acquire(blocking=False):
+            return
+        if rank == 0:
+            if timed_out:
+                extra["extras_timed_out_after_s"] = EXTRAS_DEADLINE_S
+            if extra:
+                line["extra"] = extra
+            print(json.dumps(line), flush=True)
+
+    def deadline():
+        emit(timed_out=True)
+        os._exit(0)     # a hung collective cannot be unwound; the headline line is out
+
+    do_extras = args.workload == "rk4_single" and args.n is None and args.variant < 0 and not args.no_extras and not args.no_reuse
+    if do_extras:
+        dog = threading.Timer(EXTRAS_DEADLINE_S, deadline)
+        dog.daemon = True
+        dog.start()
+
+        def guarded(name, fn):
+            try:
+                barrier()
+                fn()
+            except Exception as e:   # noqa: BLE001 - an extra must never cost the headline
+                extra[name + "_error"] = f"{type(e).__name__}: {e}"
+
+        def x_n65536():
+            w, _, r = run_rk4_single(65536, 4000, 200, args.layout, -1)
+            v = 65536.0 * 4000 * world / w
+            extra["BASELINE_configs1_rk4_N65536"] = {"value": v, "unit": "grid-point-steps/s", "n_ranks": world, "reps": r,
+                                                     "effective_frac_of_hbm_roofline_per_gpu": BYTES_PER_POINT_STEP * v / world / 1e9 / HBM_PEAK_GBS}
+
+        def x_no_reuse():
+            w, _, r = run_rk4_single(1 << 20, steps, warmup, args.layout, -1, no_reuse=True)
+            extra["rk4_N1048576_no_reuse"] = {"value": float(1 << 20) * steps * world / w, "unit": "grid-point-steps/s", "n_ranks": world,
+                                              "note": "same kernel, no evaluation may reuse the transcendentals of an earlier one (what a rough "
+                                                      "state does wave by wave): the input-independent floor of the headline"}
+
+        def x_sweep():
+            w, _, _, info = run_sweep(1024, 4096, 2000, 20, True)
+            extra["BASELINE_configs2_3_sweep_rk45"] = {"value": 1024.0 * 4096 * 2000 * world / w, "unit": "grid-point-steps/s (attempted steps)",
+                                                       "n_ranks": world, "instances_total": 4096 * world, "N": 1024, "attempts": 2000,
+                                                       "parallelism": "instances sharded evenly over the ranks; no collective", **info}
+
+        def x_dd():
+            w, _, _, info = run_dd(1 << 22, 500, 16)
+            extra["BASELINE_configs4_dd_rk45"] = {"value": float(1 << 22) * 500 / w, "unit": "grid-point-steps/s (attempted steps)",
+                                                  "n_ranks": world, "N": 1 << 22, "attempts": 500, "scaling": "strong",
+                                                  "parallelism": "1-D domain decomposition; one all-gather (halo strips + record) per attempt", **info}
+        guarded("BASELINE_configs1_rk4_N65536", x_n65536)
+        guarded("rk4_N1048576_no_reuse", x_no_reuse)
+        guarded("BASELINE_configs2_3_sweep_rk45", x_sweep)
+        guarded("BASELINE_configs4_dd_rk45", x_dd)
+        dog.cancel()
+    emit()
+    if use_dist:
+        try:
+            dist.destroy_process_group()
+        except Exception:   # noqa: BLE001
+            pass
 
 
 if __name__ == "__main__":

@@ -46,7 +46,8 @@ typedef struct marl_params {
 
 /* Integration statistics; the comparable part of scipy's OdeResult (nfev, status, t_events). */
 typedef struct marl_stats {
-    int64_t nfev;       /* RHS evaluations, counted as scipy does (1 at start + 6 per attempt) */
+    int64_t nfev;       /* RHS evaluations, counted as scipy does (RK45: 1 at start + 6 per attempt; Radau: incl. the
+                           finite-difference Jacobian columns) */
     int64_t n_accepted; /* accepted steps */
     int64_t n_rejected; /* rejected attempts */
     int32_t status;     /* 0 reached t1; -1 step size too small (scipy status -1); 2 attempt budget exhausted */
@@ -55,6 +56,8 @@ typedef struct marl_stats {
     double h_next;      /* step size the controller would try next */
     double event_value[MARL_NEVENTS];   /* the 7 monitors evaluated at the final state */
     int64_t n_events[MARL_NEVENTS];     /* sign changes seen per monitor (both directions, non-terminal) */
+    int64_t njev;       /* Jacobian evaluations (implicit Radau path; 0 for the explicit integrators) - scipy's sol.njev */
+    int64_t nlu;        /* LU decompositions, counted as scipy does (real and complex system separately) - sol.nlu */
 } marl_stats;
 
 #ifdef __cplusplus

@@ -268,18 +268,26 @@ class LMAHeureuxPorosityDiff:
 
         Returns an :class:`RK45Result` whose ``t``/``y`` hold the ``t_eval`` samples (``y``: (5N, n_t), as
         scipy) or, without ``t_eval``, the end point only; ``t_events`` is a list of 7 arrays."""
-        y = self._host_state(y0).copy()
-        n = y.size
-        stats = MarlStats()
+        y_start = self._host_state(y0)
+        n = y_start.size
         te = None if t_eval is None else np.ascontiguousarray(t_eval, dtype=np.float64)
         n_eval = 0 if te is None else te.size
-        y_eval = np.empty((max(n_eval, 1), n))
-        tev = np.full((NEVENTS, max_events), np.nan) if events else None
-        rc = self._lib.marl_integrate_rk45(
-            self._ctx, _as_ptr(y), float(t_span[0]), float(t_span[1]), float(first_step), float(rtol), float(atol),
-            _as_ptr(te) if n_eval else None, n_eval, _as_ptr(y_eval) if n_eval else None,
-            _as_ptr(tev) if events else None, max_events if events else 0, int(max_attempts), C.byref(stats))
-        self._check(rc, "marl_integrate_rk45")
+        while True:
+            y = y_start.copy()
+            stats = MarlStats()
+            y_eval = np.empty((max(n_eval, 1), n))
+            tev = np.full((NEVENTS, max_events), np.nan) if events else None
+            rc = self._lib.marl_integrate_rk45(
+                self._ctx, _as_ptr(y), float(t_span[0]), float(t_span[1]), float(first_step), float(rtol), float(atol),
+                _as_ptr(te) if n_eval else None, n_eval, _as_ptr(y_eval) if n_eval else None,
+                _as_ptr(tev) if events else None, max_events if events else 0, int(max_attempts), C.byref(stats))
+            self._check(rc, "marl_integrate_rk45")
+            most = max(stats.n_events[:]) if events else 0
+            if most <= max_events:
+                break
+            # solve_ivp returns EVERY root time (a monitor sitting at exactly 0 fires on every accepted step): the run is
+            # deterministic, so repeat it with a buffer that holds them all
+            max_events = int(most)
         t_events = None
         if events:
             t_events = [tev[e, :min(int(stats.n_events[e]), max_events)].copy() for e in range(NEVENTS)]

@@ -35,6 +35,7 @@ class MarlStats(C.Structure):
         ("status", C.c_int32), ("reserved", C.c_int32),
         ("t", C.c_double), ("h_next", C.c_double),
         ("event_value", C.c_double * NEVENTS), ("n_events", C.c_int64 * NEVENTS),
+        ("njev", C.c_int64), ("nlu", C.c_int64),
     ]
 
 

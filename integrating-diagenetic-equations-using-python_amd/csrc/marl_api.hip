@@ -39,6 +39,7 @@ struct marl_ctx {
     Rk45Ctrl* hctrl = nullptr;  // pinned
     double* hrec = nullptr;     // pinned [batch][NQ]
     double* ddt = nullptr;      // [batch] per-instance dt
+    double* hdt = nullptr;      // pinned [batch]: staging of the caller's dt array (the caller's buffer may die before the copy runs)
     // options
     int64_t rk4_variant = -1, rk45_variant = -1, sweep_variant = -1, host_layout = LAYOUT_TILED, poll = 64;
     std::string err;
@@ -152,6 +153,9 @@ static int ensure_part(marl_ctx* ctx, size_t records)
     return 0;
 }
 
+// validate_tol (scipy/integrate/_ivp/common.py:44-51): rtol below 100 eps is raised to it
+static double clamp_rtol(double rtol) { const double lo = 100 * 2.220446049250313e-16; return rtol < lo ? lo : rtol; }
+
 static int64_t state_doubles(int64_t n, int layout)
 {
     return layout == LAYOUT_TILED ? ((n + 63) / 64) * (int64_t)(NF * 64) : (int64_t)NF * n;
@@ -202,6 +206,7 @@ int marl_ctx_create(const marl_params* params, int64_t n_instances, int64_t N, i
     CREATE_OK(hipMalloc((void**)&ctx->ddt, sizeof(double) * n_instances));
     CREATE_OK(hipHostMalloc((void**)&ctx->hctrl, sizeof(Rk45Ctrl) * n_instances, hipHostMallocDefault));
     CREATE_OK(hipHostMalloc((void**)&ctx->hrec, sizeof(double) * NQ * n_instances, hipHostMallocDefault));
+    CREATE_OK(hipHostMalloc((void**)&ctx->hdt, sizeof(double) * n_instances, hipHostMallocDefault));
 #undef CREATE_OK
     *out = ctx;
     return 0;
@@ -221,6 +226,7 @@ void marl_ctx_destroy(marl_ctx* ctx)
     if (ctx->dconsts) (void)hipFree(ctx->dconsts);
     if (ctx->hctrl) (void)hipHostFree(ctx->hctrl);
     if (ctx->hrec) (void)hipHostFree(ctx->hrec);
+    if (ctx->hdt) (void)hipHostFree(ctx->hdt);
     delete ctx;
 }
 
@@ -249,6 +255,13 @@ int marl_set_option(marl_ctx* ctx, const char* name, int64_t value)
     else if (n == "sweep_variant") ctx->sweep_variant = value;
     else if (n == "host_layout") ctx->host_layout = value ? LAYOUT_TILED : LAYOUT_FIELD_MAJOR;
     else if (n == "poll_interval") ctx->poll = value > 0 ? value : 1;
+    else if (n == "no_reuse") {
+        // every evaluation of the fused kernels takes its full path (what a rough state does wave by wave): re-upload the constants
+        for (auto& c : ctx->hconsts) c.hot.no_reuse = value ? 1 : 0;
+        HIP_OK(ctx, hipSetDevice(ctx->device));
+        HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_OK(ctx, hipMemcpy(ctx->dconsts, ctx->hconsts.data(), sizeof(DevConsts) * ctx->hconsts.size(), hipMemcpyHostToDevice));
+    }
     else return fail(ctx, -1, "marl_set_option: unknown option '%s'", name);
     return 0;
 }
@@ -615,6 +628,7 @@ static int rk45_run(marl_ctx* ctx, int layout, bool small, double t0, double t1,
     if (!(first_step > 0) || !(t1 >= t0)) return fail(ctx, -1, "rk45: need first_step > 0 and t1 >= t0 (forward integration)");
     if (t1 > t0 && first_step > t1 - t0) return fail(ctx, -1, "rk45: `first_step` exceeds bounds");  // common.py:10-16
     if (!(rtol > 0) || !(atol >= 0)) return fail(ctx, -1, "rk45: tolerances must be positive");
+    rtol = clamp_rtol(rtol);
     for (int64_t i = 0; i < n_eval; i++)
         if (t_eval[i] < t0 || t_eval[i] > t1 || (i > 0 && t_eval[i] <= t_eval[i - 1]))
             return fail(ctx, -1, "rk45: `t_eval` must be sorted and within t_span");  // ivp.py:603-609
@@ -780,7 +794,11 @@ int marl_sweep_rk4_dev(marl_ctx* ctx, double* y_dev, const double* dt, int64_t n
     HIP_OK(ctx, hipSetDevice(ctx->device));
     const int v = default_sweep_variant(ctx);
     if (v < 0) return fail(ctx, -1, "marl_sweep_rk4_dev: N = %lld exceeds the largest one-workgroup window (1024 cells)", (long long)ctx->N);
-    HIP_OK(ctx, hipMemcpyAsync(ctx->ddt, dt, sizeof(double) * ctx->batch, hipMemcpyHostToDevice, ctx->stream));
+    // through the context's pinned buffer: `dt` may be a temporary of the caller (the previous use of hdt has long completed
+    // in stream order only if we wait for it - a sweep launch is milliseconds, the wait is free)
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(ctx->hdt, dt, sizeof(double) * ctx->batch);
+    HIP_OK(ctx, hipMemcpyAsync(ctx->ddt, ctx->hdt, sizeof(double) * ctx->batch, hipMemcpyHostToDevice, ctx->stream));
     const dim3 grid((unsigned)ctx->batch);
     SWEEP_DISPATCH(rk4_sweep_kernel, y_dev, ctx->dconsts, ctx->ddt, ctx->N, nsteps)
     LAUNCH_OK(ctx);
@@ -822,7 +840,7 @@ int marl_sweep_rk45_dev(marl_ctx* ctx, double* y_dev, double t0, double t1, doub
     const int v = default_sweep_variant(ctx);
     if (v < 0) return fail(ctx, -1, "marl_sweep_rk45_dev: N = %lld exceeds the largest one-workgroup window (1024 cells)", (long long)ctx->N);
     if (int rc = launch_monitors(ctx, y_dev, LAYOUT_FIELD_MAJOR)) return rc;
-    hipLaunchKernelGGL(rk45_init_kernel, dim3((unsigned)ctx->batch), dim3(1), 0, ctx->stream, ctx->dctrl, ctx->rec, t0, t1, first_step, rtol,
+    hipLaunchKernelGGL(rk45_init_kernel, dim3((unsigned)ctx->batch), dim3(1), 0, ctx->stream, ctx->dctrl, ctx->rec, t0, t1, first_step, clamp_rtol(rtol),
                        atol, (int64_t)NF * ctx->N, max_attempts, 0);
     LAUNCH_OK(ctx);
     const dim3 grid((unsigned)ctx->batch);
@@ -980,7 +998,7 @@ int marl_slab_init_control(marl_ctx* ctx, const double* recs_dev, int64_t nrec, 
     if (!(first_step > 0) || !(t1 >= t0) || (t1 > t0 && first_step > t1 - t0)) return fail(ctx, -1, "rk45: `first_step` must be in (0, t1 - t0]");
     hipLaunchKernelGGL(reduce_records_kernel, dim3(1), dim3(256), 0, ctx->stream, recs_dev, nrec, ctx->rec);
     LAUNCH_OK(ctx);
-    hipLaunchKernelGGL(rk45_init_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->dctrl, ctx->rec, t0, t1, first_step, rtol, atol,
+    hipLaunchKernelGGL(rk45_init_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->dctrl, ctx->rec, t0, t1, first_step, clamp_rtol(rtol), atol,
                        (int64_t)NF * ctx->N, max_attempts, 0);
     LAUNCH_OK(ctx);
     return 0;

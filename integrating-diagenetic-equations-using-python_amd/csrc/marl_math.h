@@ -51,7 +51,7 @@ struct HotConsts {
     int32_t fv;                      // FV_switch
     int32_t generic_p0;              // some exponent <= 0, i.e. some pow(0, e) != 0: take the general combination
     int32_t var_dphi;                // marl_params.dPhi_variable (host side: selects the VD kernel instantiation)
-    int32_t reserved;
+    int32_t no_reuse;                // option "no_reuse": no centre ever validates -> every evaluation takes the full path (bench: worst case)
 };
 
 struct DevConsts {
@@ -79,7 +79,7 @@ __device__ __forceinline__ HotConsts load_hot(const DevConsts* __restrict__ c)
     double* f = reinterpret_cast<double*>(&k);
 #pragma unroll
     for (int i = 0; i < (int)(offsetof(HotConsts, fv) / sizeof(double)); i++) f[i] = pin_uniform(f[i]);
-    asm volatile("" : "+s"(k.fv), "+s"(k.generic_p0));
+    asm volatile("" : "+s"(k.fv), "+s"(k.generic_p0), "+s"(k.no_reuse));
     return k;
 }
 
@@ -345,7 +345,8 @@ __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask
         }
         if constexpr (MODE == TR_FILL || MODE == TR_AUTO) {
             // generic_p0 (an exponent < 1 or <= 0: the clamp-pair shortcut / the bound |u| <= |n u| do not hold): never reuse
-            const double ib = K.generic_p0 ? __builtin_nan("") : rcp_nr(O2 - 1.0);
+            // (option no_reuse: the same NaN makes every later range check fail - the fallback path of every wave, always)
+            const double ib = (K.generic_p0 | K.no_reuse) ? __builtin_nan("") : rcp_nr(O2 - 1.0);
             pc.Phi = Phi; pc.O2 = O2; pc.nib = nsel * ib;
             // |x| = |d| invPhi, |y| = |d| invom, |10 d(1/Phi)| <= 12 |d| invPhi^2, |z| <= 2.2 |d| invPhi invden
             pc.cPhi = fmax(fmax(fabs(invPhi), fabs(invom)), fmax(12.0 * (invPhi * invPhi), 2.2 * fabs(invPhi * invden)));

@@ -15,6 +15,7 @@ The arithmetic is behind a small engine interface so that the driver logic is te
 reference engine injected by the tests; the product engine is :class:`HipSlabEngine` (C ABI, marl_slab_*).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -124,7 +125,8 @@ class DomainDecomposedRK45:
         if min(e - b for b, e in self.parts) < halo:
             raise ValueError(f"N = {N} is too small for {self.world} slabs with a halo of {halo} cells")
         if engine_factory is None:
-            dev = self.rank if device is None else device
+            # one process per GPU: the device is the LOCAL rank (a global rank only equals it on the first node)
+            dev = int(os.environ.get("LOCAL_RANK", self.rank)) if device is None else device
             engine_factory = lambda b, e: HipSlabEngine(pde_parms, self.N, b, e, dev, halo)  # noqa: E731
         self.engine = engine_factory(self.begin, self.end)
         e = self.engine
@@ -140,6 +142,8 @@ class DomainDecomposedRK45:
         hi_src = self.gathered[self.rank + 1] if self.rank < self.world - 1 else self.send    # upper neighbour's LOWER strip
         self.recv_lo, self.recv_hi = lo_src[8 + n:], hi_src[8:8 + n]
         self.recs = e.new_tensor(8 * self.world)
+        self.transport = ("none (one slab)" if self.world == 1 else
+                          f"torch.distributed.all_gather_into_tensor, backend {dist.get_backend(group)}")
 
     # -- communication ---------------------------------------------------------------------------
     def _exchange(self, which):

@@ -6,6 +6,8 @@ data path ("replicas of the kernel").  On each GPU one workgroup i
 entirely on-chip (marl_kernels.h, rk45_sweep_kernel).  Results can be gathered to every rank afterwards
 (control plane only).
 """
+import os
+
 import numpy as np
 
 
@@ -74,7 +76,7 @@ def run_sweep_rk45(base_parms, instances, t_span, first_step, rtol, atol, max_at
     if y0 is None:
         y0 = initial_states(base_parms, instances)
     if engine_factory is None:
-        dev = rank if device is None else device
+        dev = int(os.environ.get("LOCAL_RANK", rank)) if device is None else device   # one process per GPU
         engine_factory = lambda bp, inst: HipSweepEngine(bp, inst, dev)  # noqa: E731
     engine = engine_factory(base_parms, local)
     y, res = engine.integrate_rk45(np.asarray(y0)[lo:hi], t_span, first_step, rtol, atol, max_attempts)

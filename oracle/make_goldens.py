@@ -15,6 +15,10 @@ Groups written (all float64, little endian, .npz / .json):
                                                            <- LHeureux_model.py:162-288,290-522,524-593
   rk45_traj_*.npz         scipy solve_ivp(RK45) on the reference's fun_numba: accepted step
                           times, final state, nfev          <- marlpde/Evolve_scenario.py:104-109
+  rk45_event_*.npz        the same with a monitor that fires: scipy's t_events (root times)
+  radau_traj_*.npz        scipy solve_ivp(Radau, jac_sparsity=27 diagonals) on the reference's fun_numba - the
+                          reference's default solver: step times, nfev/njev/nlu, t_events, final state
+                                                           <- marlpde/parameters.py:150-199,213; Evolve_scenario.py:104-109
   ref_final_*.npy         last frame (5,200) of the reference's own HDF5 goldens and the
                           Matlab profile (5,201)            <- tests/Regression_test/data/*
   stub_pin_report.json    reference integrate_equations (Radau) through the stubs vs those
@@ -179,6 +183,84 @@ def gen_rk45(skip_slow):
               f"{time.time() - t_start:.1f}s")
 
 
+EVENTS = ("zeros", "zeros_CA", "zeros_CC", "ones_CA_plus_CC", "ones_Phi", "zeros_U", "zeros_W")
+
+
+def _pack_events(t_events):
+    """ragged list of 7 arrays -> (concatenated times, counts)"""
+    return np.concatenate([np.asarray(e, dtype=float) for e in t_events]), np.array([len(e) for e in t_events])
+
+
+def gen_rk45_event():
+    """scipy RK45 on the reference RHS from a state in which a monitor FIRES: a porosity dip makes min(U) negative at
+    t0, the reaction term lifts the porosity and zeros_U crosses zero (marlpde/Evolve_scenario.py:104-109, 118-145:
+    the root times are what the reference prints and stores)."""
+    N = 400
+    eq, y0, p, depths = build_model(SCENARIOS["default"], N, 1)
+    L = p["max_depth"] / p["Xstar"]
+    x = depths._axes_coords[0]
+    y = y0.reshape(5, N).copy()
+    y[4] = 0.8 - 0.04 * np.exp(-((x - 0.5 * L) / (0.08 * L)) ** 2)
+    y = y.ravel()
+    dx2 = (L / N) ** 2
+    t1 = 1000 * dx2
+    eq.last_t = 0.0
+    t_start = time.time()
+    sol = solve_ivp(eq.fun_numba, (0.0, t1), y, method="RK45", first_step=0.5 * dx2, rtol=1e-5, atol=1e-7,
+                    dense_output=True, args=[_Bar(), t1 / 1000, 0.0],
+                    events=[getattr(eq, e) for e in EVENTS])
+    tev, nev = _pack_events(sol.t_events)
+    np.savez_compressed(os.path.join(OUT, "rk45_event_default_N400.npz"), y0=y, t_span=np.array([0.0, t1]), rtol=1e-5, atol=1e-7,
+                        first_step=0.5 * dx2, step_times=np.asarray(sol.sol.ts), y_final=sol.y[:, -1], nfev=sol.nfev,
+                        status=sol.status, t_events=tev, n_events=nev)
+    print(f"rk45 event golden: {len(sol.sol.ts) - 1} accepted steps, nfev {sol.nfev}, events {nev.tolist()}, "
+          f"roots {tev.tolist()}, {time.time() - t_start:.1f}s")
+
+
+def gen_radau(skip_slow):
+    """The reference's DEFAULT solver: scipy Radau with its 27-diagonal jac_sparsity on the reference RHS, called with
+    exactly the keywords of marlpde/Evolve_scenario.py:104-109 (+ dense_output=True to read the accepted step
+    times; it does not change the stepping).  Cases = the three of tests/Regression_test/test_regression.py plus one
+    short tight-tolerance run."""
+    cases = [("A", SCENARIOS["A"], 200, {}, (0, 1)),
+             ("matlab", SCENARIOS["matlab"], 200, {}, (0, 1)),
+             ("A_N64_tight", SCENARIOS["A"], 64, {"rtol": 1e-6, "atol": 1e-8}, (0, 0.02))]
+    if not skip_slow:
+        cases.append(("high_porosity", {"Phi0": 0.8, "PhiIni": 0.8, "PhiNR": 0.8}, 200, {"first_step": 5e-7}, (0, 1)))
+    from marlpde.parameters import jacobian_sparsity
+    for name, ov, N, sov, span in cases:
+        eq, y0, p, _ = build_model(ov, N, 1)
+        eq.last_t = 0.0
+        sp = asdict(Solver()) | sov | {"t_span": span}
+        sp.pop("backend", None)
+        for k in ("lband", "uband"):
+            sp.pop(k, None)
+        sp["jac_sparsity"] = jacobian_sparsity() if N == 200 else _sparsity(N)
+        t_start = time.time()
+        sp["dense_output"] = True
+        with np.errstate(all="ignore"):
+            sol = solve_ivp(eq.fun_numba, y0=y0, **sp, t_eval=np.array(span, dtype=float),
+                            events=[getattr(eq, e) for e in EVENTS], args=[_Bar(), (span[1] - span[0]) / 100000, span[0]])
+        tev, nev = _pack_events(sol.t_events)
+        np.savez_compressed(os.path.join(OUT, f"radau_traj_{name}.npz"), y0=y0, N=N, t_span=np.array(span, dtype=float),
+                            rtol=sp["rtol"], atol=sp["atol"], first_step=sp["first_step"], step_times=np.asarray(sol.sol.ts),
+                            y_final=sol.y[:, -1], nfev=sol.nfev, njev=sol.njev, nlu=sol.nlu, status=sol.status,
+                            t_events=tev, n_events=nev, overrides=json.dumps(ov))
+        print(f"radau {name}: {len(sol.sol.ts) - 1} steps, nfev {sol.nfev} njev {sol.njev} nlu {sol.nlu} status {sol.status} "
+              f"events {nev.tolist()} {time.time() - t_start:.1f}s")
+
+
+def _sparsity(N):
+    """The reference's jacobian_sparsity() is hard-wired to the default N; the same pattern for another N
+    (marlpde/parameters.py:150-199: 27 diagonals, CA/CC rows x Phi columns zeroed)."""
+    from scipy.sparse import csr_matrix, dia_matrix, lil_matrix
+    n = 5 * N
+    offsets = [o + d for o in range(-n + N, n - N + 1, N) for d in (-1, 0, 1)]
+    pat = lil_matrix(dia_matrix((np.ones((len(offsets), n)), offsets), shape=(n, n)))
+    pat[:2 * N, 4 * N:] = 0
+    return csr_matrix(pat)
+
+
 def gen_ref_h5():
     """Reduce the reference's HDF5 fixtures to their final frames with the conda h5py."""
     code = r"""
@@ -236,13 +318,13 @@ def gen_stub_pin(skip_slow):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-slow", action="store_true")
+    ap.add_argument("--only", default="", help="comma list of groups: params,rhs,h5,stubpin,rk45,rk45event,radau")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    gen_params()
-    gen_rhs()
-    gen_ref_h5()
-    gen_stub_pin(args.skip_slow)
-    gen_rk45(args.skip_slow)
+    groups = {"params": gen_params, "rhs": gen_rhs, "h5": gen_ref_h5, "stubpin": lambda: gen_stub_pin(args.skip_slow),
+              "rk45": lambda: gen_rk45(args.skip_slow), "rk45event": gen_rk45_event, "radau": lambda: gen_radau(args.skip_slow)}
+    for g in (args.only.split(",") if args.only else groups):
+        groups[g]()
 
 
 if __name__ == "__main__":

@@ -301,8 +301,9 @@ typedef struct {
     int64_t N;
     double t_old, h;
     const double *y_old;
-    const double *K; /* 7 x 5N */
+    const double *K; /* 7 x 5N (Dormand-Prince stages), or NULL */
     double *scratch; /* 5N */
+    const double *Q; /* Radau: 5N x 3 (RadauDenseOutput, radau.py:549-572), or NULL */
 } orc_dense;
 
 /* RkDenseOutput._call_impl, rk.py:560-574:  y(t) = y_old + h * Q . [x, x^2, x^3, x^4],  Q = K^T P */
@@ -310,6 +311,12 @@ static void orc_dense_eval(const orc_dense *d, double t, double *out)
 {
     const int64_t n = NF * d->N;
     const double x = (t - d->t_old) / d->h;
+    if (d->Q) { /* RadauDenseOutput._call_impl, radau.py:557-572: y = Q . [x, x^2, x^3] + y_old  (not multiplied by h) */
+        const double p1 = x, p2 = p1 * x, p3 = p2 * x; /* np.cumprod */
+        for (int64_t i = 0; i < n; i++)
+            out[i] = ((d->Q[3 * i] * p1 + d->Q[3 * i + 1] * p2) + d->Q[3 * i + 2] * p3) + d->y_old[i];
+        return;
+    }
     double pw[4];
     pw[0] = x;
     for (int m = 1; m < 4; m++) pw[m] = pw[m - 1] * x;
@@ -389,6 +396,7 @@ int marl_oracle_rk45(const marl_params *p, int64_t N, double *y, double t0, doub
     memset(st, 0, sizeof *st);
     int64_t steps_out = 0, eval_i = 0, attempts = 0;
 
+    if (rtol < 100 * 2.220446049250313e-16) rtol = 100 * 2.220446049250313e-16;   /* validate_tol, common.py:44-51 */
     double t = t0, h_abs = first_step;                   /* rk.py:94-100 (first_step validated) */
     orc_rhs(p, &c, N, y, K);                             /* self.f = fun(t0, y0) */
     st->nfev = 1;
@@ -460,7 +468,7 @@ int marl_oracle_rk45(const marl_params *p, int64_t N, double *y, double t0, doub
         if (step_times && steps_out < max_steps_out) step_times[steps_out] = t;
         steps_out++;
 
-        orc_dense dense = {p, &c, N, t_old, h, yold, K, scratch};
+        orc_dense dense = {p, &c, N, t_old, h, yold, K, scratch, NULL};
         /* events, ivp.py:673-694 + find_active_events :131-156 (direction 0, non-terminal) */
         orc_events(p, &c, N, y, g_new);
         for (int e = 0; e < MARL_NEVENTS; e++) {
@@ -501,4 +509,562 @@ int marl_oracle_rk4_batch(const marl_params *p, int64_t batch, int64_t N, double
         if (r) rc = r;
     }
     return rc;
+}
+
+
+/* ==========================================================================================
+ * Implicit Radau IIA (order 5) exactly as scipy drives it for the reference - the reference's DEFAULT
+ * solver (marlpde/parameters.py:213; call site marlpde/Evolve_scenario.py:104-109 with
+ * jac_sparsity = the 27-diagonal pattern of marlpde/parameters.py:150-199).  Restated from
+ * scipy/integrate/_ivp/radau.py (constants :11-44, solve_collocation_system :47-130, predict_factor
+ * :133-173, Radau.__init__ :290-343, _step_impl :404-537, RadauDenseOutput :549-572) and
+ * scipy/integrate/_ivp/common.py (num_jac :268-344, _sparse_num_jac :389-451, norm :63-65).
+ *
+ * Jacobian: finite differences over column groups.  `groups[5N]` is the column grouping scipy derives from
+ * the sparsity pattern (scipy.optimize._numdiff.group_columns, a greedy colouring in a seeded random column
+ * order); the caller may pass scipy's own array, or NULL for the structured
+ * 15-colouring (3 cell residues x 5 fields).  (scipy's nfev does not count the finite-difference columns, so the
+ * grouping shows in no statistic.)  The VALUE of every Jacobian entry is the same either way: an entry
+ * (row, col) is (f(y + h e_group)[row] - f(y)[row]) / h[col], and no other column of a valid group touches `row`.
+ * Structure kept: rows (f, i) x columns (f', i-1..i+1), minus the CA/CC rows x Phi columns the reference's
+ * pattern zeroes (parameters.py:197).  (The pattern's wrap-around entries - offset +-1 diagonals crossing a field
+ * boundary - receive exact zeros from the finite differences and are not stored here.)
+ *
+ * Linear algebra: scipy factorises MU/h I - J with SuperLU; here the same matrices are ordered cell-major
+ * (5i + f: block tridiagonal, half bandwidth 9) and factorised by banded LU with partial pivoting (LAPACK
+ * dgbtf2 / dgbtrs restated).  Solutions agree to rounding, not bit for bit.
+ * ========================================================================================== */
+#include <complex.h>
+
+#define RD_KL 9
+#define RD_KU 9
+#define RD_KV (RD_KL + RD_KU)
+#define RD_LDAB (2 * RD_KL + RD_KU + 1)
+
+#define RD_DEFINE_BAND(T, SUF, ABS1)                                                                      \
+    /* LAPACK xGBTF2: ab[(kv + i - j) + j*ldab] = A(i, j); returns 0 or 1 + index of a zero pivot */       \
+    static int band_factor_##SUF(int64_t n, T *ab, int32_t *ipiv)                                         \
+    {                                                                                                     \
+        int info = 0;                                                                                     \
+        for (int64_t j = RD_KU + 1; j < (RD_KV < n ? RD_KV : n); j++)                                     \
+            for (int64_t i = RD_KV - j; i < RD_KL; i++) ab[i + j * RD_LDAB] = 0;                          \
+        int64_t ju = 0;                                                                                   \
+        for (int64_t j = 0; j < n; j++) {                                                                 \
+            if (j + RD_KV < n)                                                                            \
+                for (int64_t i = 0; i < RD_KL; i++) ab[i + (j + RD_KV) * RD_LDAB] = 0;                    \
+            const int64_t km = (RD_KL < n - 1 - j) ? RD_KL : n - 1 - j;                                   \
+            int64_t jp = 0;                                                                               \
+            double best = -1;                                                                             \
+            for (int64_t i = 0; i <= km; i++) {                                                           \
+                const double a = ABS1(ab[RD_KV + i + j * RD_LDAB]);                                       \
+                if (a > best) { best = a; jp = i; }                                                       \
+            }                                                                                             \
+            ipiv[j] = (int32_t)(jp + j);                                                                  \
+            if (ab[RD_KV + jp + j * RD_LDAB] != 0) {                                                      \
+                const int64_t cand = (j + RD_KU + jp < n - 1) ? j + RD_KU + jp : n - 1;                   \
+                if (cand > ju) ju = cand;                                                                 \
+                if (jp != 0)                                                                              \
+                    for (int64_t c = j; c <= ju; c++) {                                                   \
+                        T *a = &ab[RD_KV + jp + j - c + c * RD_LDAB], *b = &ab[RD_KV + j - c + c * RD_LDAB]; \
+                        const T tmp = *a; *a = *b; *b = tmp;                                              \
+                    }                                                                                     \
+                if (km > 0) {                                                                             \
+                    const T r = 1.0 / ab[RD_KV + j * RD_LDAB];                                            \
+                    for (int64_t i = 1; i <= km; i++) ab[RD_KV + i + j * RD_LDAB] *= r;                   \
+                    for (int64_t c = j + 1; c <= ju; c++) {                                               \
+                        const T u = ab[RD_KV + j - c + c * RD_LDAB];                                      \
+                        if (u != 0)                                                                       \
+                            for (int64_t i = 1; i <= km; i++)                                             \
+                                ab[RD_KV + j + i - c + c * RD_LDAB] -= ab[RD_KV + i + j * RD_LDAB] * u;   \
+                    }                                                                                     \
+                }                                                                                         \
+            } else if (!info) info = (int)(j + 1);                                                        \
+        }                                                                                                 \
+        return info;                                                                                      \
+    }                                                                                                     \
+    /* LAPACK xGBTRS, no transpose, one right-hand side (in place) */                                      \
+    static void band_solve_##SUF(int64_t n, const T *ab, const int32_t *ipiv, T *b)                       \
+    {                                                                                                     \
+        for (int64_t j = 0; j < n - 1; j++) {                                                             \
+            const int64_t lm = (RD_KL < n - 1 - j) ? RD_KL : n - 1 - j;                                   \
+            const int64_t l = ipiv[j];                                                                    \
+            if (l != j) { const T tmp = b[l]; b[l] = b[j]; b[j] = tmp; }                                  \
+            const T bj = b[j];                                                                            \
+            for (int64_t i = 1; i <= lm; i++) b[j + i] -= bj * ab[RD_KV + i + j * RD_LDAB];               \
+        }                                                                                                 \
+        for (int64_t j = n - 1; j >= 0; j--) {                                                            \
+            b[j] /= ab[RD_KV + j * RD_LDAB];                                                              \
+            const T bj = b[j];                                                                            \
+            const int64_t lo = (j - RD_KV > 0) ? j - RD_KV : 0;                                           \
+            for (int64_t i = j - 1; i >= lo; i--) b[i] -= bj * ab[RD_KV + i - j + j * RD_LDAB];           \
+        }                                                                                                 \
+    }
+
+#define RD_ABS_REAL(x) fabs(x)
+#define RD_ABS_CPLX(x) (fabs(creal(x)) + fabs(cimag(x)))
+RD_DEFINE_BAND(double, d, RD_ABS_REAL)
+RD_DEFINE_BAND(double complex, z, RD_ABS_CPLX)
+
+/* radau.py:11-44 */
+#define RD_S6 2.449489742783178 /* 6 ** 0.5 */
+static const double RD_T[3][3] = {{0.09443876248897524, -0.14125529502095421, 0.03002919410514742},
+                                  {0.25021312296533332, 0.20412935229379994, -0.38294211275726192},
+                                  {1, 1, 0}};
+static const double RD_TI[3][3] = {{4.17871859155190428, 0.32768282076106237, 0.52337644549944951},
+                                   {-4.17871859155190428, -0.32768282076106237, 0.47662355450055044},
+                                   {0.50287263494578682, -2.57192694985560522, 0.59603920482822492}};
+#define RD_NEWTON_MAXITER 6
+#define RD_MIN_FACTOR 0.2
+#define RD_MAX_FACTOR 10.0
+#define RD_EPS 2.220446049250313e-16
+
+typedef struct {
+    const marl_params *p;
+    const orc_consts *c;
+    int64_t N, n;
+    double *J;      /* [N][3][5][5]: J[((i*3 + d)*5 + f)*5 + fp] = d rate(f, i) / d y(fp, i + d - 1) */
+    double *factor; /* num_jac's per-column step factors (carried from call to call), or NULL before the first call */
+    const int32_t *groups;
+    int32_t n_groups;
+    int32_t *own_groups;
+    marl_stats *st;
+} rd_ctx;
+
+static void rd_fun(const rd_ctx *R, const double *y, double *out)
+{
+    orc_rhs(R->p, R->c, R->N, y, out);
+    R->st->nfev++;
+}
+
+/* The finite-difference columns go through OdeSolver.fun_vectorized, which calls the user function WITHOUT counting
+ * (scipy/integrate/_ivp/base.py:150-156): scipy's nfev excludes them. */
+static void rd_fun_uncounted(const rd_ctx *R, const double *y, double *out) { orc_rhs(R->p, R->c, R->N, y, out); }
+
+/* is (row field f) x (column field fp) in the reference's pattern?  (parameters.py:197) */
+static inline int rd_in_pattern(int f, int fp) { return !(f < 2 && fp == 4); }
+
+/* the |diff| column of one perturbed column j = (fp, ip): rows sorted as scipy's csc stores them (row index f*N + i
+ * ascending).  Returns max |diff|, the row index of its FIRST occurrence, and the diffs in dcol[f][di], di = i - ip + 1. */
+static double rd_column_diff(const rd_ctx *R, const double *f0, const double *fnew, int fp, int64_t ip, double dcol[NF][3],
+                             int64_t *max_row)
+{
+    const int64_t N = R->N;
+    double best = 0;
+    int64_t arg = -1;
+    for (int f = 0; f < NF; f++)
+        for (int di = 0; di < 3; di++) {
+            const int64_t i = ip + di - 1;
+            dcol[f][di] = 0;
+            if (i < 0 || i >= N || !rd_in_pattern(f, fp)) continue;
+            const int64_t r = f * N + i;
+            const double d = fnew[r] - f0[r];
+            dcol[f][di] = d;
+            if (arg < 0 || fabs(d) > best) { best = fabs(d); arg = r; } /* np.argmax: first occurrence */
+        }
+    /* scipy's sparse argmax: an all-zero column reports row 0 (scipy/sparse/_data.py:265-272: min(position 0, first
+     * implicit zero)) */
+    if (best == 0) arg = 0;
+    *max_row = arg;
+    return best;
+}
+
+/* num_jac + _sparse_num_jac, common.py:268-451.  f0 = fun(t, y). */
+static int rd_num_jac(rd_ctx *R, const double *y, const double *f0, double threshold)
+{
+    const int64_t n = R->n, N = R->N;
+    const double REJECT = pow(RD_EPS, 0.875), SMALL = pow(RD_EPS, 0.75), BIG = pow(RD_EPS, 0.25), MINF = 1e3 * RD_EPS;
+    const int ng = R->n_groups;
+    double *work = (double *)malloc(sizeof(double) * (size_t)(n * (6 + 2 * (size_t)ng)));
+    unsigned char *small = (unsigned char *)calloc((size_t)n + (size_t)ng, 1);
+    if (!work || !small) { free(work); free(small); return -2; }
+    double *h = work, *y_scale = work + n, *max_diff = work + 2 * n, *scale = work + 3 * n, *ys = work + 4 * n, *h_new = work + 5 * n;
+    double *fnew = work + 6 * n, *fnew2 = fnew + (size_t)ng * n;
+    unsigned char *group_hit = small + n;
+    if (!R->factor) {
+        R->factor = (double *)malloc(sizeof(double) * n);
+        if (!R->factor) { free(work); free(small); return -2; }
+        for (int64_t j = 0; j < n; j++) R->factor[j] = sqrt(RD_EPS); /* EPS ** 0.5 */
+    }
+    double *factor = R->factor;
+    R->st->njev++;
+    for (int64_t j = 0; j < n; j++) {
+        const double f_sign = (f0[j] >= 0) ? 1.0 : -1.0;
+        const double ay = fabs(y[j]);
+        y_scale[j] = f_sign * (threshold > ay ? threshold : ay); /* np.maximum(threshold, |y|) */
+        h[j] = (y[j] + factor[j] * y_scale[j]) - y[j];
+        while (h[j] == 0) { factor[j] *= 10; h[j] = (y[j] + factor[j] * y_scale[j]) - y[j]; }
+    }
+    for (int g = 0; g < ng; g++) {
+        for (int64_t j = 0; j < n; j++) ys[j] = y[j] + (R->groups[j] == g ? h[j] : 0.0);
+        rd_fun_uncounted(R, ys, fnew + (size_t)g * n);
+    }
+    int any_small = 0;
+    double *J = R->J;
+    for (int fp = 0; fp < NF; fp++)
+        for (int64_t ip = 0; ip < N; ip++) {
+            const int64_t j = fp * N + ip;
+            const double *fg = fnew + (size_t)R->groups[j] * n;
+            double dcol[NF][3];
+            int64_t mr;
+            max_diff[j] = rd_column_diff(R, f0, fg, fp, ip, dcol, &mr);
+            const double a = fabs(f0[mr]), b = fabs(fg[mr]);
+            scale[j] = a > b ? a : b;
+            for (int f = 0; f < NF; f++)
+                for (int di = 0; di < 3; di++) {
+                    const int64_t i = ip + di - 1;
+                    if (i >= 0 && i < N) J[((i * 3 + (2 - di)) * NF + f) * NF + fp] = dcol[f][di];
+                }
+            if (max_diff[j] < REJECT * scale[j]) { small[j] = 1; group_hit[R->groups[j]] = 1; any_small = 1; }
+        }
+    if (any_small) {
+        for (int64_t j = 0; j < n; j++) h_new[j] = small[j] ? (y[j] + 10 * factor[j] * y_scale[j]) - y[j] : 0.0;
+        for (int g = 0; g < ng; g++) {
+            if (!group_hit[g]) continue;
+            for (int64_t j = 0; j < n; j++) ys[j] = y[j] + (R->groups[j] == g ? h_new[j] : 0.0);
+            rd_fun_uncounted(R, ys, fnew2 + (size_t)g * n);
+        }
+        for (int fp = 0; fp < NF; fp++)
+            for (int64_t ip = 0; ip < N; ip++) {
+                const int64_t j = fp * N + ip;
+                if (!small[j]) continue;
+                const double *fg = fnew2 + (size_t)R->groups[j] * n;
+                double dcol[NF][3];
+                int64_t mr;
+                const double md_new = rd_column_diff(R, f0, fg, fp, ip, dcol, &mr);
+                const double a = fabs(f0[mr]), b = fabs(fg[mr]);
+                const double scale_new = a > b ? a : b;
+                if (max_diff[j] * scale_new < md_new * scale[j]) {
+                    factor[j] = 10 * factor[j];
+                    h[j] = h_new[j];
+                    scale[j] = scale_new;
+                    max_diff[j] = md_new;
+                    for (int f = 0; f < NF; f++)
+                        for (int di = 0; di < 3; di++) {
+                            const int64_t i = ip + di - 1;
+                            if (i >= 0 && i < N) J[((i * 3 + (2 - di)) * NF + f) * NF + fp] = dcol[f][di];
+                        }
+                }
+            }
+    }
+    for (int fp = 0; fp < NF; fp++)
+        for (int64_t ip = 0; ip < N; ip++) {
+            const int64_t j = fp * N + ip;
+            for (int f = 0; f < NF; f++)
+                for (int di = 0; di < 3; di++) {
+                    const int64_t i = ip + di - 1;
+                    if (i >= 0 && i < N) J[((i * 3 + (2 - di)) * NF + f) * NF + fp] /= h[j];
+                }
+            if (max_diff[j] < SMALL * scale[j]) factor[j] *= 10;
+            if (max_diff[j] > BIG * scale[j]) factor[j] *= 0.1;
+            if (factor[j] < MINF) factor[j] = MINF;
+        }
+    free(work);
+    free(small);
+    return 0;
+}
+
+/* band storage of  mu I - J  in the cell-major ordering 5 i + f */
+static void rd_assemble_real(const rd_ctx *R, double mu, double *ab)
+{
+    const int64_t n = R->n, N = R->N;
+    memset(ab, 0, sizeof(double) * (size_t)(RD_LDAB * n));
+    for (int64_t i = 0; i < N; i++)
+        for (int d = 0; d < 3; d++) {
+            const int64_t ic = i + d - 1;
+            if (ic < 0 || ic >= N) continue;
+            for (int f = 0; f < NF; f++)
+                for (int fp = 0; fp < NF; fp++) {
+                    const int64_t r = NF * i + f, c = NF * ic + fp;
+                    ab[RD_KV + r - c + c * RD_LDAB] = (r == c ? mu : 0.0) - R->J[((i * 3 + d) * NF + f) * NF + fp];
+                }
+        }
+}
+
+static void rd_assemble_cplx(const rd_ctx *R, double complex mu, double complex *ab)
+{
+    const int64_t n = R->n, N = R->N;
+    memset(ab, 0, sizeof(double complex) * (size_t)(RD_LDAB * n));
+    for (int64_t i = 0; i < N; i++)
+        for (int d = 0; d < 3; d++) {
+            const int64_t ic = i + d - 1;
+            if (ic < 0 || ic >= N) continue;
+            for (int f = 0; f < NF; f++)
+                for (int fp = 0; fp < NF; fp++) {
+                    const int64_t r = NF * i + f, c = NF * ic + fp;
+                    ab[RD_KV + r - c + c * RD_LDAB] = (r == c ? mu : 0.0) - R->J[((i * 3 + d) * NF + f) * NF + fp];
+                }
+        }
+}
+
+/* field-major vector <-> cell-major vector */
+static inline int64_t rd_perm(int64_t N, int64_t k) { return (k % NF) * N + k / NF; } /* cell-major index k -> field-major index */
+
+/* norm(x) = ||x||_2 / sqrt(size), common.py:63-65 */
+static double rd_rms_scaled(const double *x, const double *scale, int64_t n, int rows)
+{
+    double ss = 0;
+    for (int r = 0; r < rows; r++)
+        for (int64_t i = 0; i < n; i++) { const double v = x[r * n + i] / scale[i]; ss += v * v; }
+    return sqrt(ss) / sqrt((double)(rows * n));
+}
+
+/* predict_factor, radau.py:133-173.  *_old < 0 encodes None. */
+static double rd_predict_factor(double h_abs, double h_abs_old, double error_norm, double error_norm_old)
+{
+    double multiplier;
+    if (error_norm_old < 0 || h_abs_old < 0 || error_norm == 0) multiplier = 1;
+    else multiplier = h_abs / h_abs_old * pow(error_norm_old / error_norm, 0.25);
+    return (multiplier < 1 ? multiplier : 1) * pow(error_norm, -0.25); /* error_norm = 0 -> inf (errstate ignore) */
+}
+
+int marl_oracle_radau(const marl_params *p, int64_t N, double *y, double t0, double t1, double first_step,
+                      double rtol, double atol, const int32_t *groups,
+                      const double *t_eval, int64_t n_eval, double *y_eval,
+                      double *step_times, int64_t max_steps_out, int64_t *n_steps_out,
+                      double *t_events, int64_t max_events, int64_t max_attempts, marl_stats *st)
+{
+    orc_consts c;
+    orc_derive(p, N, &c);
+    const int64_t n = NF * N;
+    const double S6 = sqrt(6.0);
+    const double C3[3] = {(4 - S6) / 10, (4 + S6) / 10, 1};
+    const double E3[3] = {(-13 - 7 * S6) / 3, (-13 + 7 * S6) / 3, -1.0 / 3};
+    const double MU_REAL = 3 + pow(3, 2.0 / 3) - pow(3, 1.0 / 3);
+    const double complex MU_COMPLEX = (3 + 0.5 * (pow(3, 1.0 / 3) - pow(3, 2.0 / 3))) - 0.5 * I * (pow(3, 5.0 / 6) + pow(3, 7.0 / 6));
+    const double P3[3][3] = {{13.0 / 3 + 7 * S6 / 3, -23.0 / 3 - 22 * S6 / 3, 10.0 / 3 + 5 * S6},
+                             {13.0 / 3 - 7 * S6 / 3, -23.0 / 3 + 22 * S6 / 3, 10.0 / 3 - 5 * S6},
+                             {1.0 / 3, -8.0 / 3, 10.0 / 3}};
+    memset(st, 0, sizeof *st);
+    if (rtol < 100 * RD_EPS) rtol = 100 * RD_EPS; /* validate_tol, common.py:44-51 */
+
+    rd_ctx R = {p, &c, N, n, NULL, NULL, groups, 0, NULL, st};
+    if (!groups) { /* structured colouring: columns (f, i) and (f', i') never share a row when i = i' mod 3 and f = f' */
+        R.own_groups = (int32_t *)malloc(sizeof(int32_t) * n);
+        for (int64_t j = 0; j < n; j++) R.own_groups[j] = (int32_t)(3 * (j / N) + (j % N) % 3);
+        R.groups = R.own_groups;
+    }
+    for (int64_t j = 0; j < n; j++)
+        if (R.groups[j] + 1 > R.n_groups) R.n_groups = R.groups[j] + 1;
+
+    double *buf = (double *)malloc(sizeof(double) * (size_t)n * 24);
+    R.J = (double *)calloc((size_t)N * 75, sizeof(double));
+    double *ab_r = (double *)malloc(sizeof(double) * (size_t)(RD_LDAB * n));
+    double complex *ab_c = (double complex *)malloc(sizeof(double complex) * (size_t)(RD_LDAB * n));
+    double complex *rhs_c = (double complex *)malloc(sizeof(double complex) * (size_t)n);
+    int32_t *piv_r = (int32_t *)malloc(sizeof(int32_t) * n), *piv_c = (int32_t *)malloc(sizeof(int32_t) * n);
+    if (!buf || !R.J || !ab_r || !ab_c || !rhs_c || !piv_r || !piv_c) return -2;
+    double *f = buf, *fnew = buf + n, *Z = buf + 2 * n /* 3n */, *W = buf + 5 * n /* 3n */, *F = buf + 8 * n /* 3n */;
+    double *dW = buf + 11 * n /* 3n */, *Z0 = buf + 14 * n /* 3n */, *scale = buf + 17 * n, *ynew = buf + 18 * n, *err = buf + 19 * n;
+    double *yold = buf + 20 * n, *Q = buf + 21 * n /* 3n: [i][3] */;
+    double *rhs_r = (double *)malloc(sizeof(double) * (size_t)n * 3);
+    double *ys = rhs_r + n, *scratch = rhs_r + 2 * n;
+    double g[MARL_NEVENTS], g_new[MARL_NEVENTS];
+    int64_t steps_out = 0, eval_i = 0, attempts = 0;
+
+    /* Radau.__init__, radau.py:290-343 */
+    double t = t0;
+    rd_fun(&R, y, f);
+    double S_h_abs = first_step, S_h_abs_old = -1, S_err_old = -1; /* self.h_abs, self.h_abs_old, self.error_norm_old; < 0: None */
+    const double newton_tol = fmax(10 * RD_EPS / rtol, fmin(0.03, sqrt(rtol)));
+    int have_sol = 0;
+    double sol_t_old = t0, sol_h = 0;
+    if (rd_num_jac(&R, y, f, atol)) return -2;
+    int current_jac = 1, have_lu = 0;
+    orc_events(p, &c, N, y, g); /* ivp.py:645 */
+    int status = 1;
+
+    while (status == 1) {
+        if (t == t1) { status = 0; break; } /* base.py:189-194 */
+        /* ---- _step_impl, radau.py:404-537 ---- */
+        const double min_step = 10 * fabs(nextafter(t, INFINITY) - t);
+        double h_abs = S_h_abs, h_abs_o = S_h_abs_old, err_o = S_err_old;
+        if (S_h_abs < min_step) { h_abs = min_step; h_abs_o = -1; err_o = -1; } /* max_step = inf */
+        int rejected = 0, accepted = 0, n_iter = 0;
+        double rate = -1, h = 0, t_new = t, error_norm = 0, safety = 0;
+        while (!accepted) {
+            if (h_abs < min_step) { status = -1; break; }
+            if (max_attempts > 0 && attempts >= max_attempts) { status = 2; break; }
+            attempts++;
+            h = h_abs;
+            t_new = t + h;
+            if (t_new - t1 > 0) t_new = t1;
+            h = t_new - t;
+            h_abs = fabs(h);
+            if (!have_sol) {
+                memset(Z0, 0, sizeof(double) * 3 * n);
+            } else { /* Z0 = self.sol(t + h * C).T - y */
+                for (int s = 0; s < 3; s++) {
+                    const double x = ((t + h * C3[s]) - sol_t_old) / sol_h;
+                    const double p1 = x, p2 = p1 * x, p3 = p2 * x;
+                    for (int64_t i = 0; i < n; i++)
+                        Z0[s * n + i] = (((Q[3 * i] * p1 + Q[3 * i + 1] * p2) + Q[3 * i + 2] * p3) + yold[i]) - y[i];
+                }
+            }
+            for (int64_t i = 0; i < n; i++) scale[i] = atol + fabs(y[i]) * rtol;
+
+            int converged = 0;
+            while (!converged) {
+                if (!have_lu) {
+                    rd_assemble_real(&R, MU_REAL / h, ab_r);
+                    band_factor_d(n, ab_r, piv_r);
+                    st->nlu++;
+                    rd_assemble_cplx(&R, MU_COMPLEX / h, ab_c);
+                    band_factor_z(n, ab_c, piv_c);
+                    st->nlu++;
+                    have_lu = 1;
+                }
+                /* ---- solve_collocation_system, radau.py:47-130 ---- */
+                const double M_real = MU_REAL / h;
+                const double complex M_complex = MU_COMPLEX / h;
+                for (int r = 0; r < 3; r++)
+                    for (int64_t i = 0; i < n; i++)
+                        W[r * n + i] = (RD_TI[r][0] * Z0[i] + RD_TI[r][1] * Z0[n + i]) + RD_TI[r][2] * Z0[2 * n + i];
+                memcpy(Z, Z0, sizeof(double) * 3 * n);
+                double dW_norm_old = -1;
+                rate = -1;
+                int k;
+                for (k = 0; k < RD_NEWTON_MAXITER; k++) {
+                    int finite = 1;
+                    for (int s = 0; s < 3; s++) {
+                        for (int64_t i = 0; i < n; i++) ys[i] = y[i] + Z[s * n + i];
+                        rd_fun(&R, ys, F + s * n);
+                    }
+                    for (int64_t i = 0; i < 3 * n && finite; i++)
+                        if (!isfinite(F[i])) finite = 0;
+                    if (!finite) break;
+                    for (int64_t kk = 0; kk < n; kk++) { /* right-hand sides in the cell-major ordering of the band matrices */
+                        const int64_t i = rd_perm(N, kk);
+                        const double fr = (F[i] * RD_TI[0][0] + F[n + i] * RD_TI[0][1]) + F[2 * n + i] * RD_TI[0][2];
+                        rhs_r[kk] = fr - M_real * W[i];
+                        const double complex fc = (F[i] * (RD_TI[1][0] + I * RD_TI[2][0]) + F[n + i] * (RD_TI[1][1] + I * RD_TI[2][1]))
+                                                  + F[2 * n + i] * (RD_TI[1][2] + I * RD_TI[2][2]);
+                        rhs_c[kk] = fc - M_complex * (W[n + i] + I * W[2 * n + i]);
+                    }
+                    band_solve_d(n, ab_r, piv_r, rhs_r);
+                    band_solve_z(n, ab_c, piv_c, rhs_c);
+                    for (int64_t kk = 0; kk < n; kk++) {
+                        const int64_t i = rd_perm(N, kk);
+                        dW[i] = rhs_r[kk];
+                        dW[n + i] = creal(rhs_c[kk]);
+                        dW[2 * n + i] = cimag(rhs_c[kk]);
+                    }
+                    const double dW_norm = rd_rms_scaled(dW, scale, n, 3);
+                    if (dW_norm_old >= 0) rate = dW_norm / dW_norm_old;
+                    if (rate >= 0 && (rate >= 1 || pow(rate, RD_NEWTON_MAXITER - k) / (1 - rate) * dW_norm > newton_tol)) break;
+                    for (int64_t i = 0; i < 3 * n; i++) W[i] += dW[i];
+                    for (int r = 0; r < 3; r++)
+                        for (int64_t i = 0; i < n; i++)
+                            Z[r * n + i] = (RD_T[r][0] * W[i] + RD_T[r][1] * W[n + i]) + RD_T[r][2] * W[2 * n + i];
+                    if (dW_norm == 0 || (rate >= 0 && rate / (1 - rate) * dW_norm < newton_tol)) { converged = 1; break; }
+                    dW_norm_old = dW_norm;
+                }
+                n_iter = (k < RD_NEWTON_MAXITER ? k : RD_NEWTON_MAXITER - 1) + 1; /* python: k + 1 with k the last loop value */
+                if (!converged) {
+                    if (current_jac) break;
+                    if (rd_num_jac(&R, y, f, atol)) return -2;
+                    current_jac = 1;
+                    have_lu = 0;
+                }
+            }
+            if (!converged) {
+                h_abs *= 0.5;
+                have_lu = 0;
+                st->n_rejected++;
+                continue;
+            }
+            for (int64_t i = 0; i < n; i++) ynew[i] = y[i] + Z[2 * n + i];
+            /* error = solve_lu(LU_real, f + Z.T.dot(E) / h) */
+            for (int64_t kk = 0; kk < n; kk++) {
+                const int64_t i = rd_perm(N, kk);
+                const double ZE = ((Z[i] * E3[0] + Z[n + i] * E3[1]) + Z[2 * n + i] * E3[2]) / h;
+                rhs_r[kk] = f[i] + ZE;
+            }
+            band_solve_d(n, ab_r, piv_r, rhs_r);
+            for (int64_t kk = 0; kk < n; kk++) err[rd_perm(N, kk)] = rhs_r[kk];
+            for (int64_t i = 0; i < n; i++) {
+                const double a = fabs(y[i]), b = fabs(ynew[i]);
+                scale[i] = atol + ((a > b || a != a) ? a : b) * rtol;
+            }
+            error_norm = rd_rms_scaled(err, scale, n, 1);
+            safety = 0.9 * (2 * RD_NEWTON_MAXITER + 1) / (2 * RD_NEWTON_MAXITER + n_iter);
+            if (rejected && error_norm > 1) {
+                for (int64_t i = 0; i < n; i++) ys[i] = y[i] + err[i];
+                rd_fun(&R, ys, scratch);
+                for (int64_t kk = 0; kk < n; kk++) {
+                    const int64_t i = rd_perm(N, kk);
+                    const double ZE = ((Z[i] * E3[0] + Z[n + i] * E3[1]) + Z[2 * n + i] * E3[2]) / h;
+                    rhs_r[kk] = scratch[i] + ZE;
+                }
+                band_solve_d(n, ab_r, piv_r, rhs_r);
+                for (int64_t kk = 0; kk < n; kk++) err[rd_perm(N, kk)] = rhs_r[kk];
+                error_norm = rd_rms_scaled(err, scale, n, 1);
+            }
+            if (error_norm > 1) {
+                const double factor = rd_predict_factor(h_abs, h_abs_o, error_norm, err_o);
+                const double sf = safety * factor;
+                h_abs *= (sf > RD_MIN_FACTOR) ? sf : RD_MIN_FACTOR; /* max(MIN_FACTOR, x); NaN -> MIN_FACTOR */
+                have_lu = 0;
+                rejected = 1;
+                st->n_rejected++;
+            } else {
+                accepted = 1; /* (a NaN error norm is "not > 1": scipy accepts it too) */
+            }
+        }
+        if (status != 1) break;
+        const int recompute_jac = n_iter > 2 && rate > 1e-3;
+        double factor = rd_predict_factor(h_abs, h_abs_o, error_norm, err_o);
+        { const double sf = safety * factor; factor = (sf < RD_MAX_FACTOR) ? sf : RD_MAX_FACTOR; } /* min(MAX_FACTOR, x) */
+        if (!recompute_jac && factor < 1.2) factor = 1;
+        else have_lu = 0;
+        rd_fun(&R, ynew, fnew);
+        if (recompute_jac) {
+            if (rd_num_jac(&R, ynew, fnew, atol)) return -2;
+            current_jac = 1;
+        } else {
+            current_jac = 0;
+        }
+        /* radau.py:512-515: self.h_abs_old receives the value self.h_abs had when this step STARTED (the size proposed by
+         * the previous step), not the possibly reduced / clipped h_abs just used */
+        S_h_abs_old = S_h_abs;
+        S_err_old = error_norm;
+        S_h_abs = h_abs * factor;
+        st->n_accepted++;
+        memcpy(yold, y, sizeof(double) * n);
+        memcpy(y, ynew, sizeof(double) * n);
+        memcpy(f, fnew, sizeof(double) * n);
+        const double t_old = t;
+        t = t_new;
+        /* _compute_dense_output: Q = Z.T . P */
+        for (int64_t i = 0; i < n; i++)
+            for (int m = 0; m < 3; m++) Q[3 * i + m] = (Z[i] * P3[0][m] + Z[n + i] * P3[1][m]) + Z[2 * n + i] * P3[2][m];
+        have_sol = 1;
+        sol_t_old = t_old;
+        sol_h = t - t_old;
+        if (t - t1 >= 0) status = 0;
+        if (step_times && steps_out < max_steps_out) step_times[steps_out] = t;
+        steps_out++;
+
+        orc_dense dense = {p, &c, N, t_old, sol_h, yold, NULL, scratch, Q};
+        orc_events(p, &c, N, y, g_new);
+        for (int e = 0; e < MARL_NEVENTS; e++) {
+            const int up = (g[e] <= 0) && (g_new[e] >= 0), down = (g[e] >= 0) && (g_new[e] <= 0);
+            if (up || down) {
+                if (t_events && st->n_events[e] < max_events)
+                    t_events[e * max_events + st->n_events[e]] = orc_brent(&dense, e, t_old, t);
+                st->n_events[e]++;
+            }
+            g[e] = g_new[e];
+        }
+        while (t_eval && eval_i < n_eval && t_eval[eval_i] <= t) {
+            orc_dense_eval(&dense, t_eval[eval_i], y_eval + eval_i * n);
+            eval_i++;
+        }
+    }
+    st->status = status;
+    st->t = t;
+    st->h_next = S_h_abs;
+    orc_events(p, &c, N, y, st->event_value);
+    if (n_steps_out) *n_steps_out = steps_out;
+    free(buf); free(R.J); free(R.factor); free(R.own_groups); free(ab_r); free(ab_c); free(rhs_c); free(piv_r); free(piv_c); free(rhs_r);
+    return status;
 }

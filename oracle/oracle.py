@@ -36,6 +36,9 @@ def lib(omp=False):
         L.marl_oracle_rk45.argtypes = [P, I64, VP, D, D, D, D, D, VP, I64, VP, VP, I64, C.POINTER(I64), VP, I64, I64,
                                        C.POINTER(MarlStats)]
         L.marl_oracle_rk45.restype = C.c_int
+        L.marl_oracle_radau.argtypes = [P, I64, VP, D, D, D, D, D, VP, VP, I64, VP, VP, I64, C.POINTER(I64), VP, I64, I64,
+                                        C.POINTER(MarlStats)]
+        L.marl_oracle_radau.restype = C.c_int
         L.marl_oracle_rk4_batch.argtypes = [P, I64, I64, VP, VP, I64]
         L.marl_oracle_rk4_batch.restype = C.c_int
         _libs[name] = L
@@ -126,5 +129,38 @@ def rk45(P, N, y0, t0, t1, first_step, rtol, atol, t_eval=None, max_steps_out=1 
     lib(omp).marl_oracle_rk45(C.byref(P), N, _ptr(y), t0, t1, first_step, rtol, atol,
                               _ptr(te) if n_eval else None, n_eval, _ptr(y_eval), _ptr(steps), max_steps_out,
                               C.byref(nsteps), _ptr(tev), max_events, max_attempts, C.byref(st))
+    t_events = [tev[e, :min(int(st.n_events[e]), max_events)].copy() for e in range(NEVENTS)]
+    return y, st, steps[:min(nsteps.value, max_steps_out)].copy(), y_eval[:n_eval], t_events
+
+
+def scipy_groups(N):
+    """The column grouping scipy derives for the reference's 27-diagonal Jacobian pattern (marlpde/parameters.py:150-199:
+    field-major, CA/CC rows x Phi columns zeroed) - scipy.optimize._numdiff.group_columns, as Radau._validate_jac calls it
+    (radau.py:349-353).  scipy is a third-party dependency of the reference, importable here and on the GPU box."""
+    from scipy.optimize._numdiff import group_columns
+    from scipy.sparse import csc_matrix, dia_matrix, lil_matrix
+    n = 5 * N
+    offsets = [o + d for o in range(-n + N, n - N + 1, N) for d in (-1, 0, 1)]
+    pat = lil_matrix(dia_matrix((np.ones((len(offsets), n)), offsets), shape=(n, n)))
+    pat[:2 * N, 4 * N:] = 0
+    return np.ascontiguousarray(group_columns(csc_matrix(pat)), dtype=np.int32)
+
+
+def radau(P, N, y0, t0, t1, first_step, rtol, atol, groups=None, t_eval=None, max_steps_out=1 << 20, max_events=4096,
+          max_attempts=0):
+    """scipy solve_ivp(method="Radau", jac_sparsity=...) restated.  Returns (y_final, stats, step_times, y_eval, t_events);
+    stats.njev / stats.nlu as scipy counts them."""
+    y = np.array(y0, dtype=np.float64)
+    st = MarlStats()
+    te = None if t_eval is None else np.ascontiguousarray(t_eval, dtype=np.float64)
+    n_eval = 0 if te is None else te.size
+    y_eval = np.empty((max(n_eval, 1), y.size))
+    steps = np.empty(max_steps_out)
+    nsteps = C.c_int64(0)
+    tev = np.full((NEVENTS, max_events), np.nan)
+    g = None if groups is None else np.ascontiguousarray(groups, dtype=np.int32)
+    lib().marl_oracle_radau(C.byref(P), N, _ptr(y), t0, t1, first_step, rtol, atol, _ptr(g) if g is not None else None,
+                            _ptr(te) if n_eval else None, n_eval, _ptr(y_eval), _ptr(steps), max_steps_out,
+                            C.byref(nsteps), _ptr(tev), max_events, max_attempts, C.byref(st))
     t_events = [tev[e, :min(int(st.n_events[e]), max_events)].copy() for e in range(NEVENTS)]
     return y, st, steps[:min(nsteps.value, max_steps_out)].copy(), y_eval[:n_eval], t_events

@@ -105,6 +105,9 @@ def test_rhs_device_layouts_against_oracle(torch_cuda, oracle, N):
     eq.close()
 
 
+RK4_VARIANT_DEPTH = (1, 2, 1, 2, 4, 8, 4, 1, 1, 1, 4, 8, 16)   # steps per launch of kRk4Variants (marl_api.hip)
+
+
 @pytest.mark.parametrize("layout", [0, 1])
 @pytest.mark.parametrize("variant", range(13))
 def test_rk4_fused_variants_against_oracle(torch_cuda, oracle, variant, layout):
@@ -112,7 +115,8 @@ def test_rk4_fused_variants_against_oracle(torch_cuda, oracle, variant, layout):
     multiple of any tile, incl. a step count that is not a multiple of the fused depth."""
     torch = torch_cuda
     from marlpde_amd._abi import LAYOUT_FIELD_MAJOR
-    N, nsteps = 5003, 11
+    per = RK4_VARIANT_DEPTH[variant]
+    N, nsteps = 5003, 2 * per + 3      # two launches of the variant's OWN depth + a remainder chain
     p = scenario("default", N)
     eq = make_model(p)
     eq.use_stream(torch.cuda.current_stream().cuda_stream)
@@ -132,6 +136,32 @@ def test_rk4_fused_variants_against_oracle(torch_cuda, oracle, variant, layout):
         eq.convert_layout_device(yt.data_ptr(), got.data_ptr(), layout, 0)
     torch.cuda.synchronize()
     assert rel_to_max(got.cpu().numpy(), ref) <= RUN_TOL
+    eq.close()
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("N", [65536, 98304])
+def test_rk4_default_kernel_at_config2_size(torch_cuda, oracle, N, layout):
+    """BASELINE configs[1] (N = 65 536) and the largest grid that still takes the 16-steps-per-launch default: 37 steps =
+    2 launches of rk4_fused_kernel<256,1,*,16> (transcendental reuse live, expansion centre carried over 16 steps)
+    + 4 + 1, both device layouts, against the oracle; then the same with every evaluation forced onto its full path."""
+    torch = torch_cuda
+    p = scenario("default", N)
+    eq = make_model(p)
+    eq.use_stream(torch.cuda.current_stream().cuda_stream)
+    y = synthetic_state(p, N, amplitude=0.01)
+    dt = 0.25 * (eq.Depths.length / N) ** 2
+    ref = oracle.rk4(oracle.params_from_model(eq), N, y, dt, 37, omp=True)
+    for no_reuse in (0, 1):
+        eq.set_option("no_reuse", no_reuse)
+        yd = torch.from_numpy(y).cuda()
+        buf = torch.zeros(eq.state_doubles(layout), dtype=torch.float64, device="cuda")
+        eq.convert_layout_device(yd.data_ptr(), buf.data_ptr(), 0, layout)
+        eq.integrate_rk4_device(buf.data_ptr(), dt, 37, layout)
+        got = torch.empty_like(yd)
+        eq.convert_layout_device(buf.data_ptr(), got.data_ptr(), layout, 0)
+        torch.cuda.synchronize()
+        assert rel_to_max(got.cpu().numpy(), ref) <= RUN_TOL, no_reuse
     eq.close()
 
 
@@ -217,6 +247,21 @@ def test_rk45_host_entry_large_grid_t_eval_and_budget(oracle):
     res2 = eq.integrate_rk45(y, (0.0, t1), 0.4 * dx2, 1e-4, 1e-6, max_attempts=7, events=False)
     _, st2, _, _, _ = oracle.rk45(P, N, y, 0.0, t1, 0.4 * dx2, 1e-4, 1e-6, max_attempts=7)
     assert res2.status == 2 == st2.status and res2.t_reached == pytest.approx(st2.t, rel=1e-12)
+    eq.close()
+
+
+def test_rk45_event_roots_match_scipy_golden():
+    """Root times of a monitor that fires, against scipy's own t_events on the REFERENCE RHS (golden
+    rk45_event_default_N400.npz, oracle/make_goldens.py gen_rk45_event): what the reference prints and stores
+    (marlpde/Evolve_scenario.py:118-145, 175-177)."""
+    g = np.load(f"{GOLDEN}/rk45_event_default_N400.npz")
+    eq = make_model(scenario("default", 400))
+    res = eq.integrate_rk45(g["y0"], tuple(g["t_span"]), float(g["first_step"]), float(g["rtol"]), float(g["atol"]))
+    assert res.status == 0 and res.nfev == int(g["nfev"]) and res.n_accepted == len(g["step_times"]) - 1
+    assert [len(e) for e in res.t_events] == list(g["n_events"]) and sum(g["n_events"]) >= 1
+    got = np.concatenate(res.t_events)
+    assert np.allclose(got, g["t_events"], rtol=1e-9, atol=1e-12 * float(g["t_span"][1]))
+    assert rel_to_max(res.y_final, g["y_final"]) <= 1e-9
     eq.close()
 
 
@@ -354,6 +399,24 @@ def test_integrate_equations_rk45_against_reference_golden():
     assert last.shape == (5, 200) and covered == pytest.approx(13190.0) and folder is None and Xstar == 1319.0
     np.testing.assert_allclose(last, gold, rtol=0.1, atol=0.01)
     print("max abs deviation from the reference golden per field:", np.max(np.abs(last - gold), axis=1))
+
+
+def test_interior_frames_against_the_reference_stored_frames(tmp_path):
+    """The reference's HDF5 golden stores 101 frames; its tests read only the last (tests/Regression_test/
+    test_regression.py:26-27).  Scenario A with t_eval = linspace(0, 1, 101) (marlpde/parameters.py:252-261): frames 10, 25, 50
+    (t = 0.1, 0.25, 0.5 T*) at the reference's own tolerance, read back from the result file like a user would."""
+    from dataclasses import asdict, replace
+    from marlpde_amd.Evolve_scenario import integrate_equations
+    from marlpde_amd.parameters import Solver, Tracker
+    frames = np.load(f"{GOLDEN}/ref_frames_scenarioA_t0.1_0.25_0.5.npy")   # (3, 5, 200)
+    tracker = asdict(Tracker()) | {"t_eval": np.linspace(0.0, 1.0, 101), "no_t_eval": 101}
+    last, covered, _, _, folder = integrate_equations(asdict(replace(Solver(), method="RK45")), tracker, scenario("A"),
+                                                       results_root=str(tmp_path) + "/", verbose=False)
+    stored = np.load(folder + "LMAHeureuxPorosityDiff.npz")
+    assert stored["solutions"].shape == (5, 200, 101) and np.allclose(stored["times"], np.linspace(0, 1, 101))
+    for k, j in enumerate((10, 25, 50)):
+        np.testing.assert_allclose(stored["solutions"][:, :, j], frames[k], rtol=0.1, atol=0.01)
+    assert np.array_equal(stored["solutions"][:, :, -1], last)
 
 
 def _run_slabs(torch, p, N, P, y0, t1, h0, rtol, atol, max_attempts=0):

@@ -1,25 +1,50 @@
 #!/bin/bash
-# One profiling pass of the round's final state (run on the GPU box through gpurun):
-#   tools/profile_round.sh gpurun_out/r01z
-# Writes bench JSON lines of every workload, the rocprofv3 kernel-trace statistics of the default bench and the
-# PMC passes (HBM traffic: FETCH_SIZE / WRITE_SIZE, one counter per pass; SQ instruction counters) under <outdir>.
-# tools/summarize_profiles.py turns them into the files committed under profiles/.
+# One profiling pass of the round's state (run on the GPU box through gpurun):
+#   tools/profile_round.sh gpurun_out/r02a [quick]
+# Writes, under <outdir>: the bench JSON line of every workload; rocprofv3 kernel-trace statistics of every workload
+# (stats_<workload>/); PMC passes of the dominant kernels (HBM traffic: FETCH_SIZE / WRITE_SIZE, one counter per pass;
+# SQ instruction / wait counters) in pmc_<workload>_<set>/.  tools/summarize_profiles.py turns them into the files
+# committed under profiles/.  Counter passes never share a run with a trace (gpurun refuses that combination).
 set -e
 out=$1
+quick=$2
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-python bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"
+python3 bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"
 echo "bench default done"
 for w in sweep_rk45 rk45_single sweep_rk4 dd_rk45; do
-  python bench.py --no-cpu-baseline --workload $w > "$out/bench_$w.json" 2> "$out/bench_$w.err"
+  python3 bench.py --no-cpu-baseline --workload $w > "$out/bench_$w.json" 2> "$out/bench_$w.err"
 done
-python bench.py --no-cpu-baseline --n 65536 > "$out/bench_n65536.json" 2> "$out/bench_n65536.err"
+python3 bench.py --no-cpu-baseline --no-extras --n 65536 > "$out/bench_n65536.json" 2> "$out/bench_n65536.err"
 echo "benches done"
-rocprofv3 --kernel-trace --stats -d "$out/stats" --output-format csv -- python bench.py --no-cpu-baseline > "$out/stats.log" 2>&1
-echo "kernel stats done"
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c -d "$out/pmc_$c" --output-format csv -- python bench.py --no-cpu-baseline --steps 400 > "$out/pmc_$c.log" 2>&1
+[ "$quick" = "quick" ] && exit 0
+# kernel-trace statistics per workload (short runs: the trace of every dispatch is kept)
+rocprofv3 --kernel-trace --stats -d "$out/stats_default" --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras > "$out/stats_default.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$out/stats_n65536" --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras --n 65536 > "$out/stats_n65536.log" 2>&1
+for w in sweep_rk45 rk45_single sweep_rk4 dd_rk45; do
+  rocprofv3 --kernel-trace --stats -d "$out/stats_$w" --output-format csv -- python3 bench.py --no-cpu-baseline --workload $w --steps 400 > "$out/stats_$w.log" 2>&1
 done
-rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d "$out/pmc_SQ1" --output-format csv -- python bench.py --no-cpu-baseline --steps 400 > "$out/pmc_SQ1.log" 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d "$out/pmc_SQ2" --output-format csv -- python bench.py --no-cpu-baseline --steps 400 > "$out/pmc_SQ2.log" 2>&1
+echo "kernel stats done"
+SQ1="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS"
+SQ2="SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY"
+pmc() {  # pmc <tag> <counters...> -- <bench args...>
+  tag=$1; shift
+  ctr=()
+  while [ "$1" != "--" ]; do ctr+=("$1"); shift; done
+  shift
+  rocprofv3 --pmc "${ctr[@]}" -d "$out/pmc_$tag" --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras "$@" > "$out/pmc_$tag.log" 2>&1
+}
+pmc default_FETCH_SIZE FETCH_SIZE -- --steps 400
+pmc default_WRITE_SIZE WRITE_SIZE -- --steps 400
+pmc default_SQ1 $SQ1 -- --steps 400
+pmc default_SQ2 $SQ2 -- --steps 400
+pmc rk45_single_FETCH_SIZE FETCH_SIZE -- --workload rk45_single --steps 200
+pmc rk45_single_WRITE_SIZE WRITE_SIZE -- --workload rk45_single --steps 200
+pmc rk45_single_SQ1 $SQ1 -- --workload rk45_single --steps 200
+pmc rk45_single_SQ2 $SQ2 -- --workload rk45_single --steps 200
+pmc sweep_rk45_SQ1 $SQ1 -- --workload sweep_rk45 --steps 200 --warmup 5
+pmc sweep_rk45_SQ2 $SQ2 -- --workload sweep_rk45 --steps 200 --warmup 5
+pmc sweep_rk4_SQ1 $SQ1 -- --workload sweep_rk4 --steps 200 --warmup 5
+pmc n65536_SQ1 $SQ1 -- --n 65536 --steps 800
+pmc n65536_SQ2 $SQ2 -- --n 65536 --steps 800
 echo "pmc done"
