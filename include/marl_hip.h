@@ -51,7 +51,8 @@ int marl_set_stream(marl_ctx* ctx, void* hip_stream);
 int marl_synchronize(marl_ctx* ctx);
 /* Tuning knobs; unknown names are an error.  See DESIGN.md.
  *   rk4_variant, rk45_variant, sweep_variant (kernel shapes; -1 = default), host_layout (device layout used behind the
- *   host-pointer entry points), poll_interval (attempts enqueued between status reads). */
+ *   host-pointer entry points), poll_interval (attempts enqueued between status reads), no_reuse (1: every RHS evaluation of
+ *   the fused kernels takes its full transcendental path - the input-independent worst case, for benchmarks). */
 int marl_set_option(marl_ctx* ctx, const char* name, int64_t value);
 /* Derived constants of instance `inst` in the order of tests/golden/derived_constants.json:
  * delta_x nu1 nu2 KRat dCa dCO3 delta Da lambda_ auxcon rhorat0 rhorat presum F_fixed dPhi_fixed
@@ -104,6 +105,21 @@ int marl_integrate_rk45_dev(marl_ctx* ctx, double* y_dev, int layout, double t0,
  * stats: host array of n_instances entries.  FIELD-MAJOR device state.  Synchronises. */
 int marl_sweep_rk45_dev(marl_ctx* ctx, double* y_dev, double t0, double t1, double first_step, double rtol,
                         double atol, int64_t max_attempts, marl_stats* stats);
+
+/* ---- implicit Radau IIA (order 5): the reference's DEFAULT solver ------------------------------------------------
+ * Replaces  scipy.integrate.solve_ivp(fun, t_span, y0, method="Radau", jac_sparsity=jacobian_sparsity(), first_step=,
+ * rtol=, atol=, t_eval=, events=[7 monitors])  as called at marlpde/Evolve_scenario.py:104-109 with the defaults of
+ * marlpde/parameters.py:201-240 (method "Radau" :213; the 27-diagonal sparsity pattern :150-199).  Step logic:
+ * scipy/integrate/_ivp/radau.py; Jacobian: scipy's finite-difference num_jac (common.py:268-451) over column groups, with
+ * the reference's pattern (rows (f, i) x columns (f', i-1..i+1) minus CA/CC rows x Phi columns) - evaluated on the device,
+ * as are the block-tridiagonal factorisations of the real and the complex collocation system and every vector operation.
+ * groups (may be NULL): int32[5N], the column grouping scipy derives from the pattern (scipy.optimize._numdiff.group_columns);
+ * NULL selects a structured 15-colouring - the Jacobian entries are the same either way (and scipy's nfev does not count the
+ * finite-difference columns).  stats->nfev / njev / nlu are counted as scipy counts them.  Other arguments as for
+ * marl_integrate_rk45.  Single-instance contexts only. */
+int marl_integrate_radau(marl_ctx* ctx, double* y, double t0, double t1, double first_step, double rtol, double atol,
+                         const int32_t* groups, const double* t_eval, int64_t n_eval, double* y_eval, double* t_events,
+                         int64_t max_events, int64_t max_attempts, marl_stats* stats);
 
 /* ---- 1-D domain decomposition of ONE large grid (BASELINE config 5; the reference never decomposes the depth
  * axis).  One process per GPU holds a slab [g_begin, g_end) of the N_global cells in a slab context; the host

@@ -7,7 +7,10 @@ reference (Evolve_scenario.py:19) and returns the same tuple
 * ``solver_parms["backend"] == "hip"`` and ``method == "RK45"``: the whole adaptive loop
   (scipy-exact Dormand-Prince controller, the seven monitors with root finding, ``t_eval`` by dense
   output) runs on the GPU via ``marl_integrate_rk45``.
-* ``backend == "hip"`` and any other scipy method (the reference's default is the implicit ``"Radau"``):
+* ``backend == "hip"`` and ``method == "Radau"`` (the reference's default, parameters.py:213): scipy's Radau IIA step
+  logic restated natively, with the RHS, the finite-difference Jacobian (the reference's 27-diagonal pattern), the
+  block-tridiagonal LU factorisations and every vector operation on the GPU via ``marl_integrate_radau`` - no scipy in the loop.
+* ``backend == "hip"`` and any other scipy method (BDF, LSODA, ...; or ``solver_parms["scipy_driver"] = True``):
   scipy's ``solve_ivp`` drives, exactly as in the reference (:104-109), with the HIP RHS and HIP monitors
   as callables.
 * other backends: rejected - this package has no CPU implementation.
@@ -63,8 +66,26 @@ def integrate_equations(solver_parms, tracker_parms, pde_parms, results_root="..
         if status not in (0, -1):
             status = -1
         covered = Tstar * (t_span[1] if status == 0 else res.t_reached)
+    elif method == "Radau" and not solver_parms.get("scipy_driver", False):
+        # the reference's default: the whole implicit loop on the GPU (marl_integrate_radau).  The Jacobian pattern is the
+        # reference's (parameters.py:150-199); when the caller's jac_sparsity has the matching shape its scipy column grouping
+        # is used, otherwise a structured colouring - the Jacobian entries are the same either way.
+        groups = None
+        sp = solver_parms.get("jac_sparsity")
+        if sp is not None and getattr(sp, "shape", None) == (5 * N, 5 * N):
+            from scipy.optimize._numdiff import group_columns
+            from scipy.sparse import csc_matrix
+            groups = group_columns(csc_matrix(sp))
+        res = eq.integrate_radau(y0, t_span, solver_parms["first_step"], solver_parms["rtol"], solver_parms["atol"], t_eval=t_eval,
+                                 groups=groups)
+        t_out, y_out, t_events = res.t, res.y, res.t_events
+        nfev, njev, nlu, status, message = res.nfev, res.njev, res.nlu, res.status, res.message
+        if status not in (0, -1):
+            status = -1
+        covered = Tstar * (t_span[1] if status == 0 else res.t_reached)
     else:
         from scipy.integrate import solve_ivp
+        solver_parms.pop("scipy_driver", None)
         # the reference forwards every remaining Solver key to solve_ivp; keep only what the method takes
         drop = {"jac_sparsity"} if method == "LSODA" else {"lband", "uband"}
         if method not in ("Radau", "BDF", "LSODA"):

@@ -54,8 +54,8 @@ class RK45Result:
 
     def __init__(self, stats, t=None, y=None, t_events=None):
         self.nfev = int(stats.nfev)
-        self.njev = 0
-        self.nlu = 0
+        self.njev = int(stats.njev)
+        self.nlu = int(stats.nlu)
         self.n_accepted = int(stats.n_accepted)
         self.n_rejected = int(stats.n_rejected)
         # library status -> scipy status: 0 finished; -1 step size too small; 2 attempt budget (no scipy analogue)
@@ -291,6 +291,44 @@ class LMAHeureuxPorosityDiff:
         t_events = None
         if events:
             t_events = [tev[e, :min(int(stats.n_events[e]), max_events)].copy() for e in range(NEVENTS)]
+        if n_eval:
+            k = int(np.searchsorted(te, stats.t, side="right"))
+            res = RK45Result(stats, te[:k].copy(), y_eval[:k].T.copy(), t_events)
+        else:
+            res = RK45Result(stats, np.array([stats.t]), y[:, None].copy(), t_events)
+        res.y_final = y
+        return res
+
+    def integrate_radau(self, y0, t_span, first_step, rtol, atol, t_eval=None, events=True, max_events=256, max_attempts=0,
+                        groups=None):
+        """scipy ``solve_ivp(method="Radau", jac_sparsity=<the reference's 27-diagonal pattern>)`` semantics for ONE instance -
+        the reference's default solver (marlpde/parameters.py:213) - with the RHS, the finite-difference Jacobian, the
+        block-tridiagonal factorisations and all vector work on the device (marl_integrate_radau).
+
+        ``groups``: scipy's column grouping of the pattern (``scipy.optimize._numdiff.group_columns``), or None for a
+        structured 15-colouring (same Jacobian).  Returns an :class:`RK45Result` (``nfev``/``njev``/``nlu`` as scipy counts)."""
+        y_start = self._host_state(y0)
+        n = y_start.size
+        te = None if t_eval is None else np.ascontiguousarray(t_eval, dtype=np.float64)
+        n_eval = 0 if te is None else te.size
+        grp = None if groups is None else np.ascontiguousarray(groups, dtype=np.int32)
+        if grp is not None and grp.size != n:
+            raise ValueError(f"groups has {grp.size} entries, expected {n}")
+        while True:
+            y = y_start.copy()
+            stats = MarlStats()
+            y_eval = np.empty((max(n_eval, 1), n))
+            tev = np.full((NEVENTS, max_events), np.nan) if events else None
+            rc = self._lib.marl_integrate_radau(
+                self._ctx, _as_ptr(y), float(t_span[0]), float(t_span[1]), float(first_step), float(rtol), float(atol),
+                _as_ptr(grp) if grp is not None else None, _as_ptr(te) if n_eval else None, n_eval, _as_ptr(y_eval) if n_eval else None,
+                _as_ptr(tev) if events else None, max_events if events else 0, int(max_attempts), C.byref(stats))
+            self._check(rc, "marl_integrate_radau")
+            most = max(stats.n_events[:]) if events else 0
+            if most <= max_events:
+                break
+            max_events = int(most)     # scipy returns every root time: repeat the (deterministic) run with room for all
+        t_events = [tev[e, :int(stats.n_events[e])].copy() for e in range(NEVENTS)] if events else None
         if n_eval:
             k = int(np.searchsorted(te, stats.t, side="right"))
             res = RK45Result(stats, te[:k].copy(), y_eval[:k].T.copy(), t_events)

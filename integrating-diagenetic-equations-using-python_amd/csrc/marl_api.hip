@@ -12,6 +12,7 @@
 
 #include "../../include/marl_hip.h"
 #include "marl_kernels.h"
+#include "marl_radau.h"
 
 using namespace marl;
 
@@ -40,6 +41,10 @@ struct marl_ctx {
     double* hrec = nullptr;     // pinned [batch][NQ]
     double* ddt = nullptr;      // [batch] per-instance dt
     double* hdt = nullptr;      // pinned [batch]: staging of the caller's dt array (the caller's buffer may die before the copy runs)
+    // implicit (Radau) path: one device arena + a small pinned read-back area
+    double* rd_arena = nullptr;
+    size_t rd_cap = 0;
+    double* rd_host = nullptr;  // pinned: [0] norm^2, [1] flags (as int32), [2..] spare
     // options
     int64_t rk4_variant = -1, rk45_variant = -1, sweep_variant = -1, host_layout = LAYOUT_TILED, poll = 64;
     std::string err;
@@ -227,6 +232,8 @@ void marl_ctx_destroy(marl_ctx* ctx)
     if (ctx->hctrl) (void)hipHostFree(ctx->hctrl);
     if (ctx->hrec) (void)hipHostFree(ctx->hrec);
     if (ctx->hdt) (void)hipHostFree(ctx->hdt);
+    if (ctx->rd_arena) (void)hipFree(ctx->rd_arena);
+    if (ctx->rd_host) (void)hipHostFree(ctx->rd_host);
     delete ctx;
 }
 
@@ -288,19 +295,21 @@ int64_t marl_state_doubles(const marl_ctx* ctx, int layout) { return ctx ? state
 // ----------------------------------------------------------------------------------------------
 static inline int64_t inst_stride(const marl_ctx* ctx, int layout) { return state_doubles(ctx->slab.n_buf, layout); }
 
-static int launch_rhs(marl_ctx* ctx, const double* y, double* dydt, int layout)
+// nstates > 0: that many states of the ONE model of the context, one after another (implicit path); 0: one state per instance
+static int launch_rhs(marl_ctx* ctx, const double* y, double* dydt, int layout, int64_t nstates = 0)
 {
-    const dim3 grid((unsigned)((ctx->slab.n_buf + 255) / 256), (unsigned)ctx->batch);
+    const dim3 grid((unsigned)((ctx->slab.n_buf + 255) / 256), (unsigned)(nstates > 0 ? nstates : ctx->batch));
     const int64_t stride = inst_stride(ctx, layout);
+    const int cs = nstates > 0 ? 0 : 1;
     if (ctx->var_dphi) {
         if (layout == LAYOUT_TILED)
-            hipLaunchKernelGGL((rhs_kernel<LAYOUT_TILED, true>), grid, dim3(256), 0, ctx->stream, y, dydt, ctx->dconsts, ctx->slab, stride);
+            hipLaunchKernelGGL((rhs_kernel<LAYOUT_TILED, true>), grid, dim3(256), 0, ctx->stream, y, dydt, ctx->dconsts, ctx->slab, stride, cs);
         else
-            hipLaunchKernelGGL((rhs_kernel<LAYOUT_FIELD_MAJOR, true>), grid, dim3(256), 0, ctx->stream, y, dydt, ctx->dconsts, ctx->slab, stride);
+            hipLaunchKernelGGL((rhs_kernel<LAYOUT_FIELD_MAJOR, true>), grid, dim3(256), 0, ctx->stream, y, dydt, ctx->dconsts, ctx->slab, stride, cs);
     } else if (layout == LAYOUT_TILED)
-        hipLaunchKernelGGL(rhs_kernel<LAYOUT_TILED>, grid, dim3(256), 0, ctx->stream, y, dydt, ctx->dconsts, ctx->slab, stride);
+        hipLaunchKernelGGL(rhs_kernel<LAYOUT_TILED>, grid, dim3(256), 0, ctx->stream, y, dydt, ctx->dconsts, ctx->slab, stride, cs);
     else
-        hipLaunchKernelGGL(rhs_kernel<LAYOUT_FIELD_MAJOR>, grid, dim3(256), 0, ctx->stream, y, dydt, ctx->dconsts, ctx->slab, stride);
+        hipLaunchKernelGGL(rhs_kernel<LAYOUT_FIELD_MAJOR>, grid, dim3(256), 0, ctx->stream, y, dydt, ctx->dconsts, ctx->slab, stride, cs);
     LAUNCH_OK(ctx);
     return 0;
 }
@@ -1044,4 +1053,402 @@ int marl_slab_status(marl_ctx* ctx, marl_stats* stats)
 }
 
 }  // extern "C"
+// ==============================================================================================
+// Implicit path: scipy's Radau as the reference runs it by default (marlpde/parameters.py:213, jac_sparsity :150-199;
+// call site marlpde/Evolve_scenario.py:104-109).  Host = the scalar step logic of scipy/integrate/_ivp/radau.py
+// (_step_impl :404-537, solve_collocation_system :47-130, predict_factor :133-173) and of the solve_ivp driver
+// (ivp.py:654-723: events with Brent on the dense output, t_eval); device = marl_radau.h.
+// ==============================================================================================
+namespace {
+using radau::cplx;
+
+struct RadauWork {
+    double *y, *f, *fnew, *ynew, *err, *yerr, *yold, *scale, *tmp;
+    double *Z, *W, *F, *Z0, *Q, *YS;
+    double *fac, *h, *yscale, *maxdiff, *scl, *hnew, *Jraw, *YP, *FN;
+    double *J, *Dinv_r, *Up_r, *rhs_r, *out;
+    cplx *Dinv_c, *Up_c, *rhs_c;
+    int32_t *small, *groups, *flags;
+    int ng = 0;
+    bool have_factor = false;
+};
+
+int radau_alloc(marl_ctx* ctx, RadauWork& w, const int32_t* groups_host)
+{
+    const int64_t N = ctx->N, n = NF * N;
+    std::vector<int32_t> g(n);
+    if (groups_host) g.assign(groups_host, groups_host + n);
+    else for (int64_t j = 0; j < n; j++) g[j] = (int32_t)(3 * (j / N) + (j % N) % 3);   // structured colouring: 15 groups
+    int ng = 0;
+    for (int64_t j = 0; j < n; j++) {
+        if (g[j] < 0 || g[j] > 4096) return fail(ctx, -1, "radau: invalid column group %d", (int)g[j]);
+        ng = std::max(ng, g[j] + 1);
+    }
+    // a valid grouping never puts two columns that share a pattern row (same cell neighbourhood) into one group
+    for (int64_t j = 0; j < n; j++) {
+        const int64_t ip = j % N;
+        for (int fp = 0; fp < NF; fp++)
+            for (int64_t i2 = std::max<int64_t>(0, ip - 2); i2 <= std::min<int64_t>(N - 1, ip + 2); i2++) {
+                const int64_t j2 = fp * N + i2;
+                if (j2 != j && g[j2] == g[j]) return fail(ctx, -1, "radau: columns %lld and %lld share rows but are in one group", (long long)j, (long long)j2);
+            }
+    }
+    const size_t doubles = (size_t)n * (9 + 6 * 3 + 6 + 15 + 2 * (size_t)ng + 15 + 10 + 20 + 1 + 2) + 64 + (size_t)n;   // + ints
+    if (ctx->rd_cap < doubles) {
+        if (ctx->rd_arena) HIP_OK(ctx, hipFree(ctx->rd_arena));
+        ctx->rd_arena = nullptr; ctx->rd_cap = 0;
+        HIP_OK(ctx, hipMalloc((void**)&ctx->rd_arena, doubles * sizeof(double)));
+        ctx->rd_cap = doubles;
+    }
+    if (!ctx->rd_host) HIP_OK(ctx, hipHostMalloc((void**)&ctx->rd_host, 16 * sizeof(double), hipHostMallocDefault));
+    double* p = ctx->rd_arena;
+    auto take = [&](size_t k) { double* r = p; p += k; return r; };
+    w.y = take(n); w.f = take(n); w.fnew = take(n); w.ynew = take(n); w.err = take(n); w.yerr = take(n); w.yold = take(n); w.scale = take(n); w.tmp = take(n);
+    w.Z = take(3 * n); w.W = take(3 * n); w.F = take(3 * n); w.Z0 = take(3 * n); w.Q = take(3 * n); w.YS = take(3 * n);
+    w.fac = take(n); w.h = take(n); w.yscale = take(n); w.maxdiff = take(n); w.scl = take(n); w.hnew = take(n); w.Jraw = take(15 * n);
+    w.YP = take((size_t)ng * n); w.FN = take((size_t)ng * n);
+    w.J = take(15 * n); w.Dinv_r = take(5 * n); w.Up_r = take(5 * n);
+    w.Dinv_c = (cplx*)take(10 * n); w.Up_c = (cplx*)take(10 * n);
+    w.rhs_r = take(n); w.rhs_c = (cplx*)take(2 * n); w.out = take(8);
+    w.small = (int32_t*)take((n + 1) / 2 + 1); w.groups = (int32_t*)take((n + 1) / 2 + 1); w.flags = (int32_t*)take(2);
+    w.ng = ng;
+    HIP_OK(ctx, hipMemcpyAsync(w.groups, g.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));   // g dies with this frame
+    HIP_OK(ctx, hipMemsetAsync(w.J, 0, sizeof(double) * 15 * n, ctx->stream));
+    return 0;
+}
+
+inline unsigned blocks256(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+// J = finite-difference Jacobian at (y, f0)  (num_jac; njev is the caller's)
+int radau_num_jac(marl_ctx* ctx, RadauWork& w, const double* y, const double* f0, double threshold)
+{
+    const int64_t N = ctx->N, n = NF * N;
+    hipLaunchKernelGGL(radau::fd_prepare_kernel, dim3(blocks256(n)), dim3(256), 0, ctx->stream, y, f0, w.fac, threshold, w.have_factor ? 0 : 1, w.groups,
+                       w.ng, n, w.h, w.yscale, w.YP);
+    LAUNCH_OK(ctx);
+    w.have_factor = true;
+    if (int rc = launch_rhs(ctx, w.YP, w.FN, LAYOUT_FIELD_MAJOR, w.ng)) return rc;
+    hipLaunchKernelGGL(radau::fd_columns_kernel, dim3(blocks256(n)), dim3(256), 0, ctx->stream, y, f0, w.FN, w.groups, w.ng, N, w.fac, w.yscale, w.Jraw,
+                       w.maxdiff, w.scl, w.small, w.hnew, w.YP);
+    LAUNCH_OK(ctx);
+    // second trial step of the columns whose difference drowned in rounding (all groups in one launch; the columns that
+    // were fine are perturbed by 0 - scipy evaluates only the groups that need it, with the same numbers)
+    if (int rc = launch_rhs(ctx, w.YP, w.FN, LAYOUT_FIELD_MAJOR, w.ng)) return rc;
+    hipLaunchKernelGGL(radau::fd_finish_kernel, dim3(blocks256(n)), dim3(256), 0, ctx->stream, f0, w.FN, w.groups, N, w.fac, w.h, w.maxdiff, w.scl, w.small,
+                       w.hnew, w.Jraw, w.J);
+    LAUNCH_OK(ctx);
+    return 0;
+}
+
+// read back w.out[0] (a sum of squares) and the non-finite flag; resets the flag
+int radau_read(marl_ctx* ctx, RadauWork& w, double* sumsq, int* flag)
+{
+    HIP_OK(ctx, hipMemcpyAsync(ctx->rd_host, w.out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_OK(ctx, hipMemcpyAsync(ctx->rd_host + 1, w.flags, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    *sumsq = ctx->rd_host[0];
+    int32_t fl;
+    memcpy(&fl, ctx->rd_host + 1, sizeof fl);
+    if (flag) *flag = fl;
+    if (fl) HIP_OK(ctx, hipMemsetAsync(w.flags, 0, sizeof(int32_t), ctx->stream));
+    return 0;
+}
+
+int radau_monitors(marl_ctx* ctx, const double* y, double g[7])
+{
+    if (int rc = launch_monitors(ctx, y, LAYOUT_FIELD_MAJOR)) return rc;
+    HIP_OK(ctx, hipMemcpyAsync(ctx->hrec, ctx->rec, sizeof(double) * NQ, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    record_to_events(ctx->hrec, g);
+    return 0;
+}
+
+struct RadauDense { double t_old, h; };
+
+// state of the dense output at time t -> out (device)
+int radau_dense(marl_ctx* ctx, RadauWork& w, const RadauDense& d, double t, double* out)
+{
+    radau::X3 X = {{(t - d.t_old) / d.h, 0, 0}};
+    const int64_t n = NF * ctx->N;
+    hipLaunchKernelGGL(radau::dense_eval_kernel, dim3(blocks256(n)), dim3(256), 0, ctx->stream, w.Q, w.yold, (const double*)nullptr, n, X, 1, out);
+    LAUNCH_OK(ctx);
+    return 0;
+}
+
+// Brent's method for monitor e on [a, b] (solve_event_equation, ivp.py:51-76 -> scipy.optimize.brentq, xtol = rtol = 4 eps)
+int radau_brent(marl_ctx* ctx, RadauWork& w, const RadauDense& d, int e, double a, double b, double* root)
+{
+    const double xtol = 4 * 2.220446049250313e-16, rtol = xtol;
+    double g[7];
+    auto at = [&](double t, double* v) -> int {
+        if (int rc = radau_dense(ctx, w, d, t, w.tmp)) return rc;
+        if (int rc = radau_monitors(ctx, w.tmp, g)) return rc;
+        *v = g[e];
+        return 0;
+    };
+    double fa, fb;
+    if (int rc = at(a, &fa)) return rc;
+    if (int rc = at(b, &fb)) return rc;
+    if (fa == 0) { *root = a; return 0; }
+    if (fb == 0) { *root = b; return 0; }
+    double xpre = a, xcur = b, fpre = fa, fcur = fb, xblk = 0, fblk = 0, spre = 0, scur = 0;
+    for (int it = 0; it < 100; it++) {
+        if (fpre != 0 && fcur != 0 && ((fpre < 0) != (fcur < 0))) { xblk = xpre; fblk = fpre; spre = scur = xcur - xpre; }
+        if (std::fabs(fblk) < std::fabs(fcur)) { xpre = xcur; xcur = xblk; xblk = xpre; fpre = fcur; fcur = fblk; fblk = fpre; }
+        const double delta = (xtol + rtol * std::fabs(xcur)) / 2, sbis = (xblk - xcur) / 2;
+        if (fcur == 0 || std::fabs(sbis) < delta) break;
+        if (std::fabs(spre) > delta && std::fabs(fcur) < std::fabs(fpre)) {
+            double stry;
+            if (xpre == xblk) stry = -fcur * (xcur - xpre) / (fcur - fpre);
+            else {
+                const double dpre = (fpre - fcur) / (xpre - xcur), dblk = (fblk - fcur) / (xblk - xcur);
+                stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
+            }
+            if (2 * std::fabs(stry) < std::fmin(std::fabs(spre), 3 * std::fabs(sbis) - delta)) { spre = scur; scur = stry; }
+            else { spre = sbis; scur = sbis; }
+        } else { spre = sbis; scur = sbis; }
+        xpre = xcur; fpre = fcur;
+        if (std::fabs(scur) > delta) xcur += scur; else xcur += (sbis > 0 ? delta : -delta);
+        if (int rc = at(xcur, &fcur)) return rc;
+    }
+    *root = xcur;
+    return 0;
+}
+
+double radau_predict_factor(double h_abs, double h_abs_old, double error_norm, double error_norm_old)   // radau.py:133-173; < 0 = None
+{
+    double multiplier;
+    if (error_norm_old < 0 || h_abs_old < 0 || error_norm == 0) multiplier = 1;
+    else multiplier = h_abs / h_abs_old * std::pow(error_norm_old / error_norm, 0.25);
+    return (multiplier < 1 ? multiplier : 1) * std::pow(error_norm, -0.25);
+}
+
+// y0 in w.y (device, field-major).  y_eval_host: n_eval x 5N (host).  On return w.y holds the state at stats->t.
+int radau_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_step, double rtol, double atol, const double* t_eval,
+              int64_t n_eval, double* y_eval_host, double* t_events, int64_t max_events, int64_t max_attempts, marl_stats* st)
+{
+    const int64_t N = ctx->N, n = NF * N;
+    const double S6 = std::sqrt(6.0);
+    const double C3[3] = {(4 - S6) / 10, (4 + S6) / 10, 1};
+    const double E3[3] = {(-13 - 7 * S6) / 3, (-13 + 7 * S6) / 3, -1.0 / 3};
+    const double MU_REAL = 3 + std::pow(3, 2.0 / 3) - std::pow(3, 1.0 / 3);
+    const cplx MU_COMPLEX = {3 + 0.5 * (std::pow(3, 1.0 / 3) - std::pow(3, 2.0 / 3)), -0.5 * (std::pow(3, 5.0 / 6) + std::pow(3, 7.0 / 6))};
+    const radau::P33 P = {{{13.0 / 3 + 7 * S6 / 3, -23.0 / 3 - 22 * S6 / 3, 10.0 / 3 + 5 * S6},
+                           {13.0 / 3 - 7 * S6 / 3, -23.0 / 3 + 22 * S6 / 3, 10.0 / 3 - 5 * S6},
+                           {1.0 / 3, -8.0 / 3, 10.0 / 3}}};
+    constexpr int NEWTON_MAXITER = 6;
+    constexpr double MIN_FACTOR = 0.2, MAX_FACTOR = 10;
+    memset(st, 0, sizeof *st);
+    rtol = clamp_rtol(rtol);
+    const dim3 gn(blocks256(n)), b256(256);
+
+    // Radau.__init__ (radau.py:290-343)
+    double t = t0;
+    if (int rc = launch_rhs(ctx, w.y, w.f, LAYOUT_FIELD_MAJOR)) return rc;
+    st->nfev = 1;
+    double S_h_abs = first_step, S_h_abs_old = -1, S_err_old = -1;
+    const double newton_tol = std::fmax(10 * radau::EPS / rtol, std::fmin(0.03, std::sqrt(rtol)));
+    HIP_OK(ctx, hipMemsetAsync(w.flags, 0, sizeof(int32_t) * 2, ctx->stream));
+    if (int rc = radau_num_jac(ctx, w, w.y, w.f, atol)) return rc;
+    st->njev = 1;
+    bool current_jac = true, have_lu = false, have_sol = false;
+    RadauDense dense = {t0, 0};
+    double g[7], g_new[7];
+    if (int rc = radau_monitors(ctx, w.y, g)) return rc;   // ivp.py:645
+    int64_t eval_i = 0, attempts = 0;
+    int status = 1;
+
+    while (status == 1) {
+        if (t == t1) { status = 0; break; }
+        const double min_step = 10 * std::fabs(std::nextafter(t, INFINITY) - t);
+        double h_abs = S_h_abs, h_abs_o = S_h_abs_old, err_o = S_err_old;
+        if (S_h_abs < min_step) { h_abs = min_step; h_abs_o = -1; err_o = -1; }
+        bool rejected = false, accepted = false;
+        int n_iter = 0;
+        double rate = -1, h = 0, t_new = t, error_norm = 0, safety = 0;
+        while (!accepted) {
+            if (h_abs < min_step) { status = -1; break; }
+            if (max_attempts > 0 && attempts >= max_attempts) { status = 2; break; }
+            attempts++;
+            h = h_abs;
+            t_new = t + h;
+            if (t_new - t1 > 0) t_new = t1;
+            h = t_new - t;
+            h_abs = std::fabs(h);
+            if (!have_sol) {
+                HIP_OK(ctx, hipMemsetAsync(w.Z0, 0, sizeof(double) * 3 * n, ctx->stream));
+            } else {   // Z0 = self.sol(t + h * C).T - y
+                radau::X3 X;
+                for (int s = 0; s < 3; s++) X.x[s] = ((t + h * C3[s]) - dense.t_old) / dense.h;
+                hipLaunchKernelGGL(radau::dense_eval_kernel, gn, b256, 0, ctx->stream, w.Q, w.yold, (const double*)w.y, n, X, 3, w.Z0);
+                LAUNCH_OK(ctx);
+            }
+            bool converged = false;
+            while (!converged) {
+                if (!have_lu) {
+                    const cplx muc = {MU_COMPLEX.re / h, MU_COMPLEX.im / h};
+                    hipLaunchKernelGGL(radau::factor_kernel, dim3(2), dim3(64), 0, ctx->stream, w.J, N, MU_REAL / h, muc, w.Dinv_r, w.Up_r, w.Dinv_c, w.Up_c);
+                    LAUNCH_OK(ctx);
+                    st->nlu += 2;
+                    have_lu = true;
+                }
+                // ---- solve_collocation_system ----
+                const double M_real = MU_REAL / h;
+                const cplx M_c = {MU_COMPLEX.re / h, MU_COMPLEX.im / h};
+                hipLaunchKernelGGL(radau::newton_begin_kernel, gn, b256, 0, ctx->stream, w.y, w.Z0, n, rtol, atol, w.scale, w.Z, w.W, w.YS);
+                LAUNCH_OK(ctx);
+                double dW_norm_old = -1;
+                rate = -1;
+                int k;
+                for (k = 0; k < NEWTON_MAXITER; k++) {
+                    if (int rc = launch_rhs(ctx, w.YS, w.F, LAYOUT_FIELD_MAJOR, 3)) return rc;
+                    st->nfev += 3;
+                    hipLaunchKernelGGL(radau::newton_rhs_kernel, gn, b256, 0, ctx->stream, w.F, w.W, N, M_real, M_c, w.rhs_r, w.rhs_c, w.flags);
+                    LAUNCH_OK(ctx);
+                    hipLaunchKernelGGL(radau::solve_kernel, dim3(2), dim3(64), 0, ctx->stream, w.J, N, w.Dinv_r, w.Up_r, w.Dinv_c, w.Up_c, w.rhs_r, w.rhs_c, 3);
+                    LAUNCH_OK(ctx);
+                    hipLaunchKernelGGL(radau::newton_update_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.y, w.rhs_r, w.rhs_c, w.scale, N, w.W, w.Z, w.YS, w.out);
+                    LAUNCH_OK(ctx);
+                    double ss;
+                    int nonfinite;
+                    if (int rc = radau_read(ctx, w, &ss, &nonfinite)) return rc;
+                    if (nonfinite) break;   // `if not np.all(np.isfinite(F)): break` (the solve above is then unused)
+                    const double dW_norm = std::sqrt(ss) / std::sqrt((double)(3 * n));
+                    if (dW_norm_old >= 0) rate = dW_norm / dW_norm_old;
+                    if (rate >= 0 && (rate >= 1 || std::pow(rate, NEWTON_MAXITER - k) / (1 - rate) * dW_norm > newton_tol)) break;
+                    // (W += dW, Z = T W were applied by newton_update_kernel)
+                    if (dW_norm == 0 || (rate >= 0 && rate / (1 - rate) * dW_norm < newton_tol)) { converged = true; break; }
+                    dW_norm_old = dW_norm;
+                }
+                n_iter = (k < NEWTON_MAXITER ? k : NEWTON_MAXITER - 1) + 1;
+                if (!converged) {
+                    if (current_jac) break;
+                    if (int rc = radau_num_jac(ctx, w, w.y, w.f, atol)) return rc;
+                    st->njev++;
+                    current_jac = true;
+                    have_lu = false;
+                }
+            }
+            if (!converged) {
+                h_abs *= 0.5;
+                have_lu = false;
+                st->n_rejected++;
+                continue;
+            }
+            // error estimate (radau.py:466-478)
+            hipLaunchKernelGGL(radau::error_rhs_kernel, gn, b256, 0, ctx->stream, w.f, w.Z, w.y, N, E3[0], E3[1], E3[2], h, w.rhs_r, w.ynew);
+            LAUNCH_OK(ctx);
+            hipLaunchKernelGGL(radau::solve_kernel, dim3(1), dim3(64), 0, ctx->stream, w.J, N, w.Dinv_r, w.Up_r, w.Dinv_c, w.Up_c, w.rhs_r, w.rhs_c, 1);
+            LAUNCH_OK(ctx);
+            hipLaunchKernelGGL(radau::error_norm_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.rhs_r, w.y, w.ynew, N, rtol, atol, w.err, w.yerr, w.out);
+            LAUNCH_OK(ctx);
+            double ss;
+            if (int rc = radau_read(ctx, w, &ss, nullptr)) return rc;
+            error_norm = std::sqrt(ss) / std::sqrt((double)n);
+            safety = 0.9 * (2 * NEWTON_MAXITER + 1) / (2 * NEWTON_MAXITER + n_iter);
+            if (rejected && error_norm > 1) {
+                if (int rc = launch_rhs(ctx, w.yerr, w.tmp, LAYOUT_FIELD_MAJOR)) return rc;   // fun(t, y + error)
+                st->nfev++;
+                hipLaunchKernelGGL(radau::error_rhs_kernel, gn, b256, 0, ctx->stream, w.tmp, w.Z, w.y, N, E3[0], E3[1], E3[2], h, w.rhs_r, w.ynew);
+                LAUNCH_OK(ctx);
+                hipLaunchKernelGGL(radau::solve_kernel, dim3(1), dim3(64), 0, ctx->stream, w.J, N, w.Dinv_r, w.Up_r, w.Dinv_c, w.Up_c, w.rhs_r, w.rhs_c, 1);
+                LAUNCH_OK(ctx);
+                hipLaunchKernelGGL(radau::error_norm_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.rhs_r, w.y, w.ynew, N, rtol, atol, w.err, w.yerr, w.out);
+                LAUNCH_OK(ctx);
+                if (int rc = radau_read(ctx, w, &ss, nullptr)) return rc;
+                error_norm = std::sqrt(ss) / std::sqrt((double)n);
+            }
+            if (error_norm > 1) {
+                const double sf = safety * radau_predict_factor(h_abs, h_abs_o, error_norm, err_o);
+                h_abs *= (sf > MIN_FACTOR) ? sf : MIN_FACTOR;
+                have_lu = false;
+                rejected = true;
+                st->n_rejected++;
+            } else {
+                accepted = true;
+            }
+        }
+        if (status != 1) break;
+        const bool recompute_jac = n_iter > 2 && rate > 1e-3;
+        double factor = radau_predict_factor(h_abs, h_abs_o, error_norm, err_o);
+        { const double sf = safety * factor; factor = (sf < MAX_FACTOR) ? sf : MAX_FACTOR; }
+        if (!recompute_jac && factor < 1.2) factor = 1;
+        else have_lu = false;
+        if (int rc = launch_rhs(ctx, w.ynew, w.fnew, LAYOUT_FIELD_MAJOR)) return rc;
+        st->nfev++;
+        if (recompute_jac) {
+            if (int rc = radau_num_jac(ctx, w, w.ynew, w.fnew, atol)) return rc;
+            st->njev++;
+            current_jac = true;
+        } else {
+            current_jac = false;
+        }
+        S_h_abs_old = S_h_abs;      // radau.py:512: the value self.h_abs had when this step started
+        S_err_old = error_norm;
+        S_h_abs = h_abs * factor;
+        st->n_accepted++;
+        std::swap(w.yold, w.y);      // y_old = y
+        std::swap(w.y, w.ynew);      // y = y_new   (w.ynew now holds the state before last: scratch)
+        std::swap(w.f, w.fnew);
+        const double t_old = t;
+        t = t_new;
+        hipLaunchKernelGGL(radau::dense_q_kernel, gn, b256, 0, ctx->stream, w.Z, n, P, w.Q);
+        LAUNCH_OK(ctx);
+        have_sol = true;
+        dense = {t_old, t - t_old};
+        if (t - t1 >= 0) status = 0;
+
+        // events (ivp.py:673-694) and t_eval (ivp.py:706-723)
+        if (int rc = radau_monitors(ctx, w.y, g_new)) return rc;
+        for (int e = 0; e < 7; e++) {
+            const bool up = g[e] <= 0 && g_new[e] >= 0, down = g[e] >= 0 && g_new[e] <= 0;
+            if (up || down) {
+                if (t_events && st->n_events[e] < max_events) {
+                    double root;
+                    if (int rc = radau_brent(ctx, w, dense, e, t_old, t, &root)) return rc;
+                    t_events[e * max_events + st->n_events[e]] = root;
+                }
+                st->n_events[e]++;
+            }
+            g[e] = g_new[e];
+        }
+        while (t_eval && eval_i < n_eval && t_eval[eval_i] <= t) {
+            if (int rc = radau_dense(ctx, w, dense, t_eval[eval_i], w.tmp)) return rc;
+            HIP_OK(ctx, hipMemcpyAsync(y_eval_host + eval_i * n, w.tmp, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+            eval_i++;
+        }
+    }
+    st->status = status;
+    st->t = t;
+    st->h_next = S_h_abs;
+    if (int rc = radau_monitors(ctx, w.y, st->event_value)) return rc;
+    return 0;
+}
+}  // namespace
+
+extern "C" int marl_integrate_radau(marl_ctx* ctx, double* y, double t0, double t1, double first_step, double rtol, double atol,
+                                    const int32_t* groups, const double* t_eval, int64_t n_eval, double* y_eval, double* t_events,
+                                    int64_t max_events, int64_t max_attempts, marl_stats* stats)
+{
+    if (!ctx || !y || !stats || (n_eval > 0 && (!t_eval || !y_eval))) return ctx ? fail(ctx, -1, "marl_integrate_radau: invalid argument") : -1;
+    if (ctx->batch != 1 || ctx->halo > 0) return fail(ctx, -1, "marl_integrate_radau: single-instance, whole-grid context required");
+    if (!(first_step > 0) || !(t1 >= t0)) return fail(ctx, -1, "radau: need first_step > 0 and t1 >= t0 (forward integration)");
+    if (t1 > t0 && first_step > t1 - t0) return fail(ctx, -1, "radau: `first_step` exceeds bounds");   // common.py:10-16
+    if (!(rtol > 0) || !(atol >= 0)) return fail(ctx, -1, "radau: tolerances must be positive");
+    for (int64_t i = 0; i < n_eval; i++)
+        if (t_eval[i] < t0 || t_eval[i] > t1 || (i > 0 && t_eval[i] <= t_eval[i - 1]))
+            return fail(ctx, -1, "radau: `t_eval` must be sorted and within t_span");
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    RadauWork w;
+    if (int rc = radau_alloc(ctx, w, groups)) return rc;
+    const size_t n = (size_t)NF * ctx->N;
+    HIP_OK(ctx, hipMemcpyAsync(w.y, y, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = radau_run(ctx, w, t0, t1, first_step, rtol, atol, t_eval, n_eval, y_eval, t_events, max_events, max_attempts, stats)) return rc;
+    HIP_OK(ctx, hipMemcpyAsync(y, w.y, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 #endif  // MARL_LAB

@@ -202,13 +202,15 @@ __device__ __forceinline__ void block_reduce(double (&q)[NQ], double* scratch)
 // Stand-alone RHS: dydt = f(y).  The drop-in for the reference's fun / fun_numba callable
 // (marlpde/LHeureux_model.py:162, :290).  One thread per cell, neighbours straight from L1/L2.
 // ---------------------------------------------------------------------------------------------
+// blockIdx.y: instance (state at y + blockIdx.y * inst_stride, constants consts[blockIdx.y * const_stride]; const_stride = 0:
+// several states of ONE model - the stage states / finite-difference columns of the implicit path)
 template <int LAYOUT, bool VD = false>
 __global__ void __launch_bounds__(256) rhs_kernel(const double* __restrict__ y, double* __restrict__ dydt,
-                                                  const DevConsts* __restrict__ consts, Slab S, int64_t inst_stride)
+                                                  const DevConsts* __restrict__ consts, Slab S, int64_t inst_stride, int const_stride)
 {
     __shared__ double tabs[TABLE_DOUBLES];
     const Tables T = load_tables(tabs, 256);
-    const DevConsts& C = consts[blockIdx.y];
+    const DevConsts& C = consts[blockIdx.y * const_stride];
     y += blockIdx.y * inst_stride;
     dydt += blockIdx.y * inst_stride;
     const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;

@@ -1,0 +1,433 @@
+// marl_radau.h - device side of the implicit path: scipy's Radau IIA (order 5) as the reference runs it by default
+// (marlpde/parameters.py:213 method "Radau" with the 27-diagonal jac_sparsity of :150-199; call site
+// marlpde/Evolve_scenario.py:104-109; algorithm scipy/integrate/_ivp/radau.py and num_jac of common.py:268-451).
+//
+// The step logic (Newton convergence tests, step-size prediction, Jacobian / factorisation reuse) is scalar work and
+// lives on the host (marl_api.hip, radau_run); everything that touches a vector or the Jacobian is a kernel here:
+//   * finite-difference Jacobian over column groups: perturbed states for ALL groups are evaluated by ONE batched launch of
+//     rhs_kernel; the per-column bookkeeping of num_jac (difference quality test, second trial step, step-factor adaptation)
+//     runs one thread per column;
+//   * the Jacobian is kept as N x 3 blocks of 5 x 5 (cell-major unknowns make mu I - J block tridiagonal); the real and the
+//     complex system of the Radau collocation equations are factorised by block Thomas elimination with partial pivoting
+//     inside the 5 x 5 diagonal blocks (Gauss-Jordan, explicit block inverses), real and complex concurrently in two
+//     workgroups; the elimination is sequential in depth - one lane per system (a sweep of instances maps to lanes);
+//   * Newton right-hand sides, updates, norms, dense output are element-wise kernels.
+#pragma once
+#include "marl_kernels.h"
+
+namespace marl {
+namespace radau {
+
+constexpr double EPS = 2.220446049250313e-16;
+// radau.py:11-44
+constexpr double T00 = 0.09443876248897524, T01 = -0.14125529502095421, T02 = 0.03002919410514742;
+constexpr double T10 = 0.25021312296533332, T11 = 0.20412935229379994, T12 = -0.38294211275726192;
+constexpr double T20 = 1, T21 = 1, T22 = 0;
+constexpr double TI00 = 4.17871859155190428, TI01 = 0.32768282076106237, TI02 = 0.52337644549944951;
+constexpr double TI10 = -4.17871859155190428, TI11 = -0.32768282076106237, TI12 = 0.47662355450055044;
+constexpr double TI20 = 0.50287263494578682, TI21 = -2.57192694985560522, TI22 = 0.59603920482822492;
+
+struct cplx {
+    double re, im;
+};
+__host__ __device__ inline cplx operator+(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
+__host__ __device__ inline cplx operator-(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
+__host__ __device__ inline cplx operator*(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__host__ __device__ inline cplx operator*(double a, cplx b) { return {a * b.re, a * b.im}; }
+__device__ inline double abs1(double a) { return fabs(a); }
+__device__ inline double abs1(cplx a) { return fabs(a.re) + fabs(a.im); }   // LAPACK's cabs1
+__device__ inline double recip(double a) { return 1.0 / a; }
+__device__ inline cplx recip(cplx a) { const double d = 1.0 / (a.re * a.re + a.im * a.im); return {a.re * d, -a.im * d}; }
+__device__ inline double lift(double a, double) { return a; }
+__device__ inline cplx lift(double a, cplx) { return {a, 0.0}; }
+
+// cell-major index kk = 5 i + f  <->  field-major index f N + i
+__device__ __forceinline__ int64_t to_field_major(int64_t kk, int64_t N) { return (kk % NF) * N + kk / NF; }
+
+// is (row field f) x (column field fp) in the reference's pattern?  (parameters.py:197 zeroes the CA, CC rows x Phi columns)
+__device__ __forceinline__ bool in_pattern(int f, int fp) { return !(f < 2 && fp == 4); }
+
+// ---- finite-difference Jacobian (num_jac, common.py:268-344; _sparse_num_jac :389-451) -----------------------------
+// step sizes + the perturbed state of every group:  YP[g][j] = y[j] + (groups[j] == g ? h[j] : 0)
+__global__ void __launch_bounds__(256) fd_prepare_kernel(const double* __restrict__ y, const double* __restrict__ f0, double* __restrict__ factor,
+                                                         double threshold, int first, const int32_t* __restrict__ groups, int ng, int64_t n,
+                                                         double* __restrict__ h, double* __restrict__ yscale, double* __restrict__ YP)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    double fac = first ? sqrt(EPS) : factor[j];
+    const double yj = y[j];
+    const double f_sign = (f0[j] >= 0) ? 1.0 : -1.0;
+    const double ay = fabs(yj);
+    const double ys = f_sign * (threshold > ay ? threshold : ay);
+    double hj = (yj + fac * ys) - yj;
+    while (hj == 0) { fac *= 10; hj = (yj + fac * ys) - yj; }
+    factor[j] = fac; h[j] = hj; yscale[j] = ys;
+    const int gj = groups[j];
+    for (int g = 0; g < ng; g++) YP[(int64_t)g * n + j] = (g == gj) ? yj + hj : yj;
+}
+
+// |diff| column of one perturbed column j = (fp, ip) in scipy's csc row order; returns max |diff|, FIRST arg max (row index)
+__device__ __forceinline__ double fd_column(const double* __restrict__ f0, const double* __restrict__ fg, int fp, int64_t ip, int64_t N,
+                                            double (&dcol)[15], int64_t& arg)
+{
+    double best = 0;
+    arg = -1;
+#pragma unroll
+    for (int f = 0; f < NF; f++)
+#pragma unroll
+        for (int di = 0; di < 3; di++) {
+            const int64_t i = ip + di - 1;
+            double d = 0;
+            if (i >= 0 && i < N && in_pattern(f, fp)) {
+                const int64_t r = f * N + i;
+                d = fg[r] - f0[r];
+                if (arg < 0 || fabs(d) > best) { best = fabs(d); arg = r; }
+            }
+            dcol[f * 3 + di] = d;
+        }
+    if (best == 0) arg = 0;   // scipy's sparse argmax reports row 0 for an all-zero column (scipy/sparse/_data.py:265-272)
+    return best;
+}
+
+// first pass over the columns: differences, their quality, the second trial step of the columns whose difference drowned
+__global__ void __launch_bounds__(256) fd_columns_kernel(const double* __restrict__ y, const double* __restrict__ f0, const double* __restrict__ FN,
+                                                         const int32_t* __restrict__ groups, int ng, int64_t N, const double* __restrict__ factor,
+                                                         const double* __restrict__ yscale, double* __restrict__ Jraw, double* __restrict__ maxdiff,
+                                                         double* __restrict__ scl, int32_t* __restrict__ small, double* __restrict__ hnew,
+                                                         double* __restrict__ YP2)
+{
+    const int64_t n = NF * N;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const int fp = (int)(j / N);
+    const int64_t ip = j % N;
+    const int gj = groups[j];
+    const double* fg = FN + (int64_t)gj * n;
+    double dcol[15];
+    int64_t arg;
+    const double md = fd_column(f0, fg, fp, ip, N, dcol, arg);
+    const double a = fabs(f0[arg]), b = fabs(fg[arg]);
+    const double sc = a > b ? a : b;
+#pragma unroll
+    for (int e = 0; e < 15; e++) Jraw[j * 15 + e] = dcol[e];
+    maxdiff[j] = md; scl[j] = sc;
+    const bool sm = md < pow(EPS, 0.875) * sc;   // NUM_JAC_DIFF_REJECT
+    small[j] = sm ? 1 : 0;
+    const double yj = y[j];
+    const double hn = sm ? (yj + (10 * factor[j]) * yscale[j]) - yj : 0.0;
+    hnew[j] = hn;
+    for (int g = 0; g < ng; g++) YP2[(int64_t)g * n + j] = (g == gj) ? yj + hn : yj;
+}
+
+// second pass: adopt the larger step where it resolves the column better, divide by h, adapt the factors, scatter into blocks
+//   J[((i*3 + d)*5 + f)*5 + fp] = d rate(f, i) / d y(fp, i + d - 1)
+__global__ void __launch_bounds__(256) fd_finish_kernel(const double* __restrict__ f0, const double* __restrict__ FN2, const int32_t* __restrict__ groups,
+                                                        int64_t N, double* __restrict__ factor, double* __restrict__ h, const double* __restrict__ maxdiff,
+                                                        const double* __restrict__ scl, const int32_t* __restrict__ small, const double* __restrict__ hnew,
+                                                        const double* __restrict__ Jraw, double* __restrict__ J)
+{
+    const int64_t n = NF * N;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const int fp = (int)(j / N);
+    const int64_t ip = j % N;
+    double dcol[15];
+#pragma unroll
+    for (int e = 0; e < 15; e++) dcol[e] = Jraw[j * 15 + e];
+    double md = maxdiff[j], sc = scl[j], fac = factor[j], hj = h[j];
+    if (small[j]) {
+        const double* fg = FN2 + (int64_t)groups[j] * n;
+        double dnew[15];
+        int64_t arg;
+        const double md_new = fd_column(f0, fg, fp, ip, N, dnew, arg);
+        const double a = fabs(f0[arg]), b = fabs(fg[arg]);
+        const double sc_new = a > b ? a : b;
+        if (md * sc_new < md_new * sc) {
+            fac = 10 * fac; hj = hnew[j]; sc = sc_new; md = md_new;
+#pragma unroll
+            for (int e = 0; e < 15; e++) dcol[e] = dnew[e];
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < NF; f++)
+#pragma unroll
+        for (int di = 0; di < 3; di++) {
+            const int64_t i = ip + di - 1;
+            if (i >= 0 && i < N) J[((i * 3 + (2 - di)) * NF + f) * NF + fp] = dcol[f * 3 + di] / hj;
+        }
+    if (md < pow(EPS, 0.75) * sc) fac *= 10;     // NUM_JAC_DIFF_SMALL -> FACTOR_INCREASE
+    if (md > pow(EPS, 0.25) * sc) fac *= 0.1;    // NUM_JAC_DIFF_BIG   -> FACTOR_DECREASE
+    if (fac < 1e3 * EPS) fac = 1e3 * EPS;        // NUM_JAC_MIN_FACTOR
+    factor[j] = fac; h[j] = hj;
+}
+
+// ---- block-tridiagonal LU of  mu I - J  (cell-major ordering) -----------------------------------------------------------
+// Block Thomas: D'_0 = D_0; Up_i = D'_i^-1 U_i; D'_{i+1} = D_{i+1} - L_{i+1} Up_i, with D_i = mu I - J[i][1], L_i = -J[i][0],
+// U_i = -J[i][2].  D'_i is inverted by Gauss-Jordan with partial pivoting.  Stored: Dinv[i] (5x5), Up[i] (5x5).
+template <class T>
+__device__ void factor_system(const double* __restrict__ J, int64_t N, T mu, T* __restrict__ Dinv, T* __restrict__ Up)
+{
+    T Uprev[NF][NF];
+    for (int64_t i = 0; i < N; i++) {
+        T A[NF][2 * NF];
+        const double* Jd = J + (i * 3 + 1) * 25;
+        const double* Jl = J + (i * 3 + 0) * 25;
+#pragma unroll
+        for (int r = 0; r < NF; r++)
+#pragma unroll
+            for (int c = 0; c < NF; c++) {
+                T a = lift(-Jd[r * NF + c], mu);
+                if (r == c) a = a + mu;
+                if (i > 0) {
+#pragma unroll
+                    for (int k = 0; k < NF; k++) a = a + Jl[r * NF + k] * Uprev[k][c];   // - L Up,  L = -Jl
+                }
+                A[r][c] = a;
+                A[r][NF + c] = lift(r == c ? 1.0 : 0.0, mu);
+            }
+#pragma unroll
+        for (int k = 0; k < NF; k++) {
+            int p = k;
+            double best = abs1(A[k][k]);
+#pragma unroll
+            for (int r = k + 1; r < NF; r++) {
+                const double a = abs1(A[r][k]);
+                if (a > best) { best = a; p = r; }
+            }
+#pragma unroll
+            for (int r = k + 1; r < NF; r++) {
+                const bool s = (p == r);
+#pragma unroll
+                for (int c = 0; c < 2 * NF; c++) {
+                    const T t = A[k][c];
+                    A[k][c] = s ? A[r][c] : t;
+                    A[r][c] = s ? t : A[r][c];
+                }
+            }
+            const T inv = recip(A[k][k]);
+#pragma unroll
+            for (int c = 0; c < 2 * NF; c++) A[k][c] = A[k][c] * inv;
+#pragma unroll
+            for (int r = 0; r < NF; r++) {
+                if (r == k) continue;
+                const T m = A[r][k];
+#pragma unroll
+                for (int c = 0; c < 2 * NF; c++) A[r][c] = A[r][c] - m * A[k][c];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NF; r++)
+#pragma unroll
+            for (int c = 0; c < NF; c++) Dinv[i * 25 + r * NF + c] = A[r][NF + c];
+        if (i < N - 1) {
+            const double* Ju = J + (i * 3 + 2) * 25;
+#pragma unroll
+            for (int r = 0; r < NF; r++)
+#pragma unroll
+                for (int c = 0; c < NF; c++) {
+                    T a = lift(0.0, mu);
+#pragma unroll
+                    for (int k = 0; k < NF; k++) a = a - Ju[k * NF + c] * A[r][NF + k];   // Dinv * U,  U = -Ju
+                    Uprev[r][c] = a;
+                    Up[i * 25 + r * NF + c] = a;
+                }
+        }
+    }
+}
+
+// x (cell-major, in place): forward  b'_i = Dinv_i (b_i - L_i b'_{i-1}),  backward  x_i = b'_i - Up_i x_{i+1}
+template <class T>
+__device__ void solve_system(const double* __restrict__ J, int64_t N, const T* __restrict__ Dinv, const T* __restrict__ Up, T* __restrict__ x)
+{
+    T prev[NF];
+    for (int64_t i = 0; i < N; i++) {
+        T t[NF];
+        const double* Jl = J + (i * 3 + 0) * 25;
+#pragma unroll
+        for (int r = 0; r < NF; r++) {
+            T a = x[i * NF + r];
+            if (i > 0) {
+#pragma unroll
+                for (int k = 0; k < NF; k++) a = a + Jl[r * NF + k] * prev[k];
+            }
+            t[r] = a;
+        }
+#pragma unroll
+        for (int r = 0; r < NF; r++) {
+            T a = Dinv[i * 25 + r * NF] * t[0];
+#pragma unroll
+            for (int k = 1; k < NF; k++) a = a + Dinv[i * 25 + r * NF + k] * t[k];
+            prev[r] = a;
+        }
+#pragma unroll
+        for (int r = 0; r < NF; r++) x[i * NF + r] = prev[r];
+    }
+    for (int64_t i = N - 2; i >= 0; i--) {
+        T cur[NF];
+#pragma unroll
+        for (int r = 0; r < NF; r++) {
+            T a = x[i * NF + r];
+#pragma unroll
+            for (int k = 0; k < NF; k++) a = a - Up[i * 25 + r * NF + k] * prev[k];
+            cur[r] = a;
+        }
+#pragma unroll
+        for (int r = 0; r < NF; r++) { prev[r] = cur[r]; x[i * NF + r] = cur[r]; }
+    }
+}
+
+// block 0: real system (mu_r), block 1: complex system (mu_c) - concurrently
+__global__ void __launch_bounds__(64) factor_kernel(const double* __restrict__ J, int64_t N, double mu_r, cplx mu_c, double* __restrict__ Dinv_r,
+                                                    double* __restrict__ Up_r, cplx* __restrict__ Dinv_c, cplx* __restrict__ Up_c)
+{
+    if (threadIdx.x != 0) return;
+    if (blockIdx.x == 0) factor_system<double>(J, N, mu_r, Dinv_r, Up_r);
+    else factor_system<cplx>(J, N, mu_c, Dinv_c, Up_c);
+}
+
+// which: bit 0 real system, bit 1 complex system.  Results scattered to dW (field-major): dW[0] = x_r, dW[1] = Re x_c, dW[2] = Im x_c
+__global__ void __launch_bounds__(64) solve_kernel(const double* __restrict__ J, int64_t N, const double* __restrict__ Dinv_r, const double* __restrict__ Up_r,
+                                                   const cplx* __restrict__ Dinv_c, const cplx* __restrict__ Up_c, double* __restrict__ rhs_r,
+                                                   cplx* __restrict__ rhs_c, int which)
+{
+    if (threadIdx.x != 0) return;
+    const int sys = (which == 3) ? (int)blockIdx.x : (which == 1 ? 0 : 1);
+    if (sys == 0) solve_system<double>(J, N, Dinv_r, Up_r, rhs_r);
+    else solve_system<cplx>(J, N, Dinv_c, Up_c, rhs_c);
+}
+
+// ---- element-wise pieces of solve_collocation_system (radau.py:47-130) and _step_impl (:404-537) -------------------------
+// scale = atol + |y| rtol;  Z = Z0, W = TI Z0, YS = y + Z
+__global__ void __launch_bounds__(256) newton_begin_kernel(const double* __restrict__ y, const double* __restrict__ Z0, int64_t n, double rtol, double atol,
+                                                           double* __restrict__ scale, double* __restrict__ Z, double* __restrict__ W, double* __restrict__ YS)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double yi = y[i], z0 = Z0[i], z1 = Z0[n + i], z2 = Z0[2 * n + i];
+    scale[i] = atol + fabs(yi) * rtol;
+    Z[i] = z0; Z[n + i] = z1; Z[2 * n + i] = z2;
+    W[i] = (TI00 * z0 + TI01 * z1) + TI02 * z2;
+    W[n + i] = (TI10 * z0 + TI11 * z1) + TI12 * z2;
+    W[2 * n + i] = (TI20 * z0 + TI21 * z1) + TI22 * z2;
+    YS[i] = yi + z0; YS[n + i] = yi + z1; YS[2 * n + i] = yi + z2;
+}
+
+// right-hand sides of the two linear systems, in the cell-major ordering of the block matrices; flags[0] |= non-finite F
+__global__ void __launch_bounds__(256) newton_rhs_kernel(const double* __restrict__ F, const double* __restrict__ W, int64_t N, double M_real, cplx M_c,
+                                                         double* __restrict__ rhs_r, cplx* __restrict__ rhs_c, int32_t* __restrict__ flags)
+{
+    const int64_t n = NF * N;
+    const int64_t kk = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (kk >= n) return;
+    const int64_t i = to_field_major(kk, N);
+    const double f0 = F[i], f1 = F[n + i], f2 = F[2 * n + i];
+    if (!(isfinite(f0) && isfinite(f1) && isfinite(f2))) atomicOr(flags, 1);
+    rhs_r[kk] = ((f0 * TI00 + f1 * TI01) + f2 * TI02) - M_real * W[i];
+    const cplx w = {W[n + i], W[2 * n + i]};
+    const cplx fc = {(f0 * TI10 + f1 * TI11) + f2 * TI12, (f0 * TI20 + f1 * TI21) + f2 * TI22};
+    rhs_c[kk] = fc - M_c * w;
+}
+
+// one workgroup: out[0] = sum (dW / scale)^2 over the 3n entries; then W += dW, Z = T W, YS = y + Z (kept only if the host
+// goes on: a `break` of the Newton loop discards W and Z anyway, radau.py:112-119)
+__global__ void __launch_bounds__(1024) newton_update_kernel(const double* __restrict__ y, const double* __restrict__ rhs_r, const cplx* __restrict__ rhs_c,
+                                                             const double* __restrict__ scale, int64_t N, double* __restrict__ W, double* __restrict__ Z,
+                                                             double* __restrict__ YS, double* __restrict__ out)
+{
+    __shared__ double red[1024];
+    const int64_t n = NF * N;
+    double ss = 0;
+    for (int64_t kk = threadIdx.x; kk < n; kk += 1024) {
+        const int64_t i = to_field_major(kk, N);
+        const double d0 = rhs_r[kk], d1 = rhs_c[kk].re, d2 = rhs_c[kk].im;
+        const double s = scale[i];
+        const double e0 = d0 / s, e1 = d1 / s, e2 = d2 / s;
+        ss += (e0 * e0 + e1 * e1) + e2 * e2;
+        const double w0 = W[i] + d0, w1 = W[n + i] + d1, w2 = W[2 * n + i] + d2;
+        W[i] = w0; W[n + i] = w1; W[2 * n + i] = w2;
+        const double z0 = (T00 * w0 + T01 * w1) + T02 * w2, z1 = (T10 * w0 + T11 * w1) + T12 * w2, z2 = (T20 * w0 + T21 * w1) + T22 * w2;
+        Z[i] = z0; Z[n + i] = z1; Z[2 * n + i] = z2;
+        const double yi = y[i];
+        YS[i] = yi + z0; YS[n + i] = yi + z1; YS[2 * n + i] = yi + z2;
+    }
+    red[threadIdx.x] = ss;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// right-hand side of the error estimate: fvec + Z^T E / h  (radau.py:468-470, :476), cell-major; also y_new = y + Z[2]
+__global__ void __launch_bounds__(256) error_rhs_kernel(const double* __restrict__ fvec, const double* __restrict__ Z, const double* __restrict__ y, int64_t N,
+                                                        double E0, double E1, double E2, double h, double* __restrict__ rhs_r, double* __restrict__ ynew)
+{
+    const int64_t n = NF * N;
+    const int64_t kk = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (kk >= n) return;
+    const int64_t i = to_field_major(kk, N);
+    const double ZE = ((Z[i] * E0 + Z[n + i] * E1) + Z[2 * n + i] * E2) / h;
+    rhs_r[kk] = fvec[i] + ZE;
+    ynew[i] = y[i] + Z[2 * n + i];
+}
+
+// one workgroup: err (field-major) = solution; scale = atol + max(|y|, |y_new|) rtol; out[0] = sum (err / scale)^2; yerr = y + err
+__global__ void __launch_bounds__(1024) error_norm_kernel(const double* __restrict__ rhs_r, const double* __restrict__ y, const double* __restrict__ ynew,
+                                                          int64_t N, double rtol, double atol, double* __restrict__ err, double* __restrict__ yerr,
+                                                          double* __restrict__ out)
+{
+    __shared__ double red[1024];
+    const int64_t n = NF * N;
+    double ss = 0;
+    for (int64_t kk = threadIdx.x; kk < n; kk += 1024) {
+        const int64_t i = to_field_major(kk, N);
+        const double e = rhs_r[kk];
+        const double a = fabs(y[i]), b = fabs(ynew[i]);
+        const double s = atol + ((a > b || a != a) ? a : b) * rtol;
+        const double q = e / s;
+        ss += q * q;
+        err[i] = e;
+        yerr[i] = y[i] + e;
+    }
+    red[threadIdx.x] = ss;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// dense output coefficients Q = Z^T P (radau.py:539-541), stored [i][3]
+struct P33 { double p[3][3]; };
+__global__ void __launch_bounds__(256) dense_q_kernel(const double* __restrict__ Z, int64_t n, P33 P, double* __restrict__ Q)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double z0 = Z[i], z1 = Z[n + i], z2 = Z[2 * n + i];
+#pragma unroll
+    for (int m = 0; m < 3; m++) Q[3 * i + m] = (z0 * P.p[0][m] + z1 * P.p[1][m]) + z2 * P.p[2][m];
+}
+
+// RadauDenseOutput._call_impl (radau.py:557-572) at up to three times x[s] = (t_s - t_old) / h_old:
+//   out[s][i] = (Q[i] . [x, x^2, x^3] + y_old[i]) - sub[i]      (sub = NULL: nothing subtracted)
+struct X3 { double x[3]; };
+__global__ void __launch_bounds__(256) dense_eval_kernel(const double* __restrict__ Q, const double* __restrict__ yold, const double* __restrict__ sub,
+                                                         int64_t n, X3 X, int ns, double* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double q0 = Q[3 * i], q1 = Q[3 * i + 1], q2 = Q[3 * i + 2], yo = yold[i];
+    const double sb = sub ? sub[i] : 0.0;
+    for (int s = 0; s < ns; s++) {
+        const double p1 = X.x[s], p2 = p1 * p1, p3 = p2 * p1;
+        double v = ((q0 * p1 + q1 * p2) + q2 * p3) + yo;
+        if (sub) v = v - sb;
+        out[(int64_t)s * n + i] = v;
+    }
+}
+
+}  // namespace radau
+}  // namespace marl

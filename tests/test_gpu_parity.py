@@ -541,7 +541,8 @@ def test_scipy_driven_radau_with_hip_rhs():
     from marlpde_amd.Evolve_scenario import integrate_equations
     from marlpde_amd.parameters import Solver, Tracker
     gold = np.load(f"{GOLDEN}/ref_final_scenarioA_Phi0_0.6_PhiIni_0.5.npy")
-    last, covered, *_ = integrate_equations(asdict(Solver()), asdict(Tracker()), scenario("A"), results_root=None, verbose=False)
+    last, covered, *_ = integrate_equations(asdict(Solver()) | {"scipy_driver": True}, asdict(Tracker()), scenario("A"), results_root=None,
+                                            verbose=False)
     assert covered == pytest.approx(13190.0)
     np.testing.assert_allclose(last, gold, rtol=0.1, atol=0.01)
     assert np.max(np.abs(last - gold)) < 1e-3      # the stub-hosted reference itself is within 7e-5 of this golden

@@ -1,0 +1,107 @@
+"""GPU parity of the implicit path: marl_integrate_radau - scipy's Radau IIA as the reference runs it by
+default (marlpde/parameters.py:213 with the jac_sparsity of :150-199), RHS / finite-difference Jacobian / block-tridiagonal LU /
+vector work on the device - against
+  * scipy itself on the REFERENCE RHS (goldens radau_traj_*.npz from oracle/make_goldens.py): same nfev / njev / nlu and step
+    sequence on the well-conditioned cases,
+  * the oracle's restatement (tests/test_oracle_radau.py pins that one),
+  * the reference's three HDF5 regression files through the drop-in driver, at the reference's own tolerances - these ARE
+    Radau results (tests/Regression_test/test_regression.py:43-53, 73-88, 114-148).
+
+Tolerances: the device RHS differs from numpy's in the last bits (FMA, table-driven log/exp); the finite-difference Jacobian
+divides those differences by h ~ 1e-8 |y|, and Newton stops at tolerance 0.03, so states agree to ~1e-7, not to rounding; step
+times to 1e-5 relative.  The high-porosity run crosses the pole Phi = 1: decisions flip after ~40 steps on ANY change of
+rounding (the oracle already differs from scipy there), so only its first steps, its statistics (5 %) and its final profile are
+compared."""
+import json
+
+import numpy as np
+import pytest
+
+from common import GOLDEN, scenario
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(name):
+    from dataclasses import asdict
+    from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
+    from marlpde_amd.parameters import Map_Scenario
+    g = np.load(f"{GOLDEN}/radau_traj_{name}.npz")
+    p = asdict(Map_Scenario()) | json.loads(str(g["overrides"])) | {"N": int(g["N"])}
+    return g, p, LMAHeureuxPorosityDiff.from_scenario(p, device=0)
+
+
+@pytest.mark.parametrize("groups", ["scipy", None])
+@pytest.mark.parametrize("name", ["A", "matlab", "A_N64_tight"])
+def test_radau_reproduces_scipy_on_the_reference_rhs(oracle, name, groups):
+    g, p, eq = _model(name)
+    N = int(g["N"])
+    grp = oracle.scipy_groups(N) if groups == "scipy" else None
+    res = eq.integrate_radau(g["y0"], tuple(g["t_span"]), float(g["first_step"]), float(g["rtol"]), float(g["atol"]), t_eval=g["t_span"],
+                             groups=grp)
+    assert res.status == 0
+    assert (res.nfev, res.njev, res.nlu) == (int(g["nfev"]), int(g["njev"]), int(g["nlu"]))
+    assert res.n_accepted == len(g["step_times"]) - 1
+    assert np.max(np.abs(res.y_final - g["y_final"])) <= 1e-6
+    assert np.array_equal(res.y[:, 0], g["y0"]) and np.max(np.abs(res.y[:, -1] - g["y_final"])) <= 1e-6
+    assert [len(e) for e in res.t_events] == list(g["n_events"])
+    if sum(g["n_events"]):   # min(CA) grazes zero with slope ~2e-4: ill-conditioned root (see tests/test_oracle_radau.py)
+        assert np.max(np.abs(np.concatenate(res.t_events) - g["t_events"])) <= 5e-4
+    # the same run by the oracle: closer than scipy (same restated algorithm; banded LU there, block Thomas here)
+    y, st, *_ = oracle.radau(oracle.params_from_dict(p), N, g["y0"], *g["t_span"], float(g["first_step"]), float(g["rtol"]), float(g["atol"]),
+                             groups=grp)
+    assert (res.nfev, res.njev, res.nlu, res.n_rejected) == (st.nfev, st.njev, st.nlu, st.n_rejected)
+    assert np.max(np.abs(res.y_final - y)) <= 1e-6
+    eq.close()
+
+
+def test_radau_high_porosity_case(oracle):
+    g, p, eq = _model("high_porosity")
+    res = eq.integrate_radau(g["y0"], tuple(g["t_span"]), float(g["first_step"]), float(g["rtol"]), float(g["atol"]), max_events=512)
+    assert res.status == 0
+    for mine, ref in ((res.nfev, g["nfev"]), (res.njev, g["njev"]), (res.nlu, g["nlu"]), (res.n_accepted, len(g["step_times"]) - 1)):
+        assert abs(mine - int(ref)) <= 0.05 * int(ref), (mine, int(ref))
+    assert np.max(np.abs(res.y_final - g["y_final"])) <= 1e-4
+    assert res.t_events[4].size == 2 and np.allclose(res.t_events[4], g["t_events"][:2], atol=1e-4)   # porosity crosses one twice
+    gold = np.load(f"{GOLDEN}/ref_final_high_porosity_0.8.npy")
+    np.testing.assert_allclose(res.y_final.reshape(5, 200), gold, rtol=0.1, atol=0.01)
+    eq.close()
+
+
+@pytest.mark.parametrize("name,gold_file,first_step", [("A", "ref_final_scenarioA_Phi0_0.6_PhiIni_0.5.npy", 1e-6),
+                                                        ("matlab", "ref_matlab_Phi_0.5_k3_k4_0.01.npy", 1e-6),
+                                                        ("default", "ref_final_high_porosity_0.8.npy", 5e-7)])
+def test_reference_regression_cases_with_the_default_solver(name, gold_file, first_step):
+    """The reference's three regression tests, as written there: integrate_equations(asdict(Solver()), asdict(Tracker()),
+    asdict(Map_Scenario()) | overrides) with the DEFAULT method (Radau) - no scipy in the loop here."""
+    import sys
+    from dataclasses import asdict, replace
+    from marlpde_amd.Evolve_scenario import integrate_equations
+    from marlpde_amd.parameters import Solver, Tracker
+    solver = asdict(replace(Solver(), first_step=first_step))
+    assert solver["method"] == "Radau" and solver["backend"] == "hip"
+    gold = np.load(f"{GOLDEN}/{gold_file}")
+    before = set(sys.modules)
+    last, covered, *_ = integrate_equations(solver, asdict(Tracker()), scenario(name), results_root=None, verbose=False)
+    assert not any(m.startswith("scipy.integrate._ivp") for m in set(sys.modules) - before), "scipy's solvers must not be in the loop"
+    assert covered == pytest.approx(13190.0) and last.shape == (5, 200)
+    if name == "matlab":
+        xs = (np.arange(200) + 0.5) * 2.5
+        interp = np.stack([np.interp(xs, np.linspace(0, 500, 201), gold[f]) for f in range(5)])
+        np.testing.assert_allclose(last[:, 2:], interp[:, 2:], atol=0.05)
+    else:
+        np.testing.assert_allclose(last, gold, rtol=0.1, atol=0.01)
+        assert np.max(np.abs(last - gold)) < 2e-4    # the stub-hosted reference itself is within 1e-4 of these files
+
+
+def test_radau_api_errors_and_budget(oracle):
+    from marlpde_amd._abi import MarlError
+    g, p, eq = _model("A")
+    with pytest.raises(MarlError, match="first_step"):
+        eq.integrate_radau(g["y0"], (0.0, 1.0), 2.0, 1e-3, 1e-3)
+    with pytest.raises(MarlError, match="share rows"):
+        eq.integrate_radau(g["y0"], (0.0, 1.0), 1e-6, 1e-3, 1e-3, groups=np.zeros(1000, dtype=np.int32))
+    res = eq.integrate_radau(g["y0"], (0.0, 1.0), 1e-6, 1e-3, 1e-3, max_attempts=5)
+    y, st, *_ = oracle.radau(oracle.params_from_dict(p), 200, g["y0"], 0.0, 1.0, 1e-6, 1e-3, 1e-3, max_attempts=5)
+    assert res.status == 2 == st.status and res.n_accepted == st.n_accepted and res.t_reached == pytest.approx(st.t, rel=1e-9)
+    eq.close()
