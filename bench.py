@@ -157,14 +157,18 @@ def main():
         fn_warm()
 
         def one():
-            barrier()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            t0 = time.perf_counter()
+            barrier()
             e0.record(stream)
+            t0 = time.perf_counter()
             fn_block()
             e1.record(stream)
+            while not e1.query():     # notice completion by polling, then the contract's synchronize (the work is complete: it
+                pass                  # returns at once) - the rank's time is taken here, the MAX over ranks afterwards
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
             barrier()
-            return time.perf_counter() - t0, e0.elapsed_time(e1)
+            return dt, e0.elapsed_time(e1)
         first = one()
         t_first = max_over_ranks([first[0]])[0]            # the same number of blocks on every rank
         reps = min(MAX_REPS, max(1, math.ceil(MIN_TIMED_S / max(t_first, 1e-7)))) if repeat else 1

@@ -262,7 +262,7 @@ class LMAHeureuxPorosityDiff:
         self._check(self._lib.marl_sweep_rk4_dev(self._ctx, C.c_void_p(y_dev_ptr), _as_ptr(dt), int(nsteps)),
                     "marl_sweep_rk4_dev")
 
-    def integrate_rk45(self, y0, t_span, first_step, rtol, atol, t_eval=None, events=True, max_events=256,
+    def integrate_rk45(self, y0, t_span, first_step, rtol, atol, t_eval=None, events=True, max_events=4096,
                        max_attempts=0):
         """scipy ``solve_ivp(method="RK45")`` semantics for ONE instance, entirely on the device.
 
@@ -299,7 +299,7 @@ class LMAHeureuxPorosityDiff:
         res.y_final = y
         return res
 
-    def integrate_radau(self, y0, t_span, first_step, rtol, atol, t_eval=None, events=True, max_events=256, max_attempts=0,
+    def integrate_radau(self, y0, t_span, first_step, rtol, atol, t_eval=None, events=True, max_events=4096, max_attempts=0,
                         groups=None):
         """scipy ``solve_ivp(method="Radau", jac_sparsity=<the reference's 27-diagonal pattern>)`` semantics for ONE instance -
         the reference's default solver (marlpde/parameters.py:213) - with the RHS, the finite-difference Jacobian, the

@@ -47,6 +47,7 @@ struct marl_ctx {
     double* rd_host = nullptr;  // pinned: [0] norm^2, [1] flags (as int32), [2..] spare
     // options
     int64_t rk4_variant = -1, rk45_variant = -1, sweep_variant = -1, host_layout = LAYOUT_TILED, poll = 64;
+    int64_t radau_solver = 0;   // 0: block parallel cyclic reduction (parallel over depth); 1: sequential block Thomas
     std::string err;
 };
 
@@ -262,6 +263,7 @@ int marl_set_option(marl_ctx* ctx, const char* name, int64_t value)
     else if (n == "sweep_variant") ctx->sweep_variant = value;
     else if (n == "host_layout") ctx->host_layout = value ? LAYOUT_TILED : LAYOUT_FIELD_MAJOR;
     else if (n == "poll_interval") ctx->poll = value > 0 ? value : 1;
+    else if (n == "radau_solver") ctx->radau_solver = value ? 1 : 0;
     else if (n == "no_reuse") {
         // every evaluation of the fused kernels takes its full path (what a rough state does wave by wave): re-upload the constants
         for (auto& c : ctx->hconsts) c.hot.no_reuse = value ? 1 : 0;
@@ -1071,6 +1073,11 @@ struct RadauWork {
     int32_t *small, *groups, *flags;
     int ng = 0;
     bool have_factor = false;
+    // block parallel cyclic reduction (default linear solver)
+    radau::PcrSystem<double> Sr{};
+    radau::PcrSystem<cplx> Sc{};
+    int nlevels = 0;
+    bool pcr = true;
 };
 
 int radau_alloc(marl_ctx* ctx, RadauWork& w, const int32_t* groups_host)
@@ -1093,7 +1100,10 @@ int radau_alloc(marl_ctx* ctx, RadauWork& w, const int32_t* groups_host)
                 if (j2 != j && g[j2] == g[j]) return fail(ctx, -1, "radau: columns %lld and %lld share rows but are in one group", (long long)j, (long long)j2);
             }
     }
-    const size_t doubles = (size_t)n * (9 + 6 * 3 + 6 + 15 + 2 * (size_t)ng + 15 + 10 + 20 + 1 + 2) + 64 + (size_t)n;   // + ints
+    int nlev = 0;
+    while (((int64_t)1 << nlev) < N) nlev++;
+    const size_t pcr_real = (size_t)N * 25 * (8 + 2 * (size_t)nlev) + 2 * (size_t)n;   // L, D, U, Dinv ping-pong; alpha, gamma per level; b ping-pong
+    const size_t doubles = (size_t)n * (9 + 6 * 3 + 6 + 15 + 2 * (size_t)ng + 15 + 10 + 20 + 1 + 2) + 64 + (size_t)n + 3 * pcr_real;
     if (ctx->rd_cap < doubles) {
         if (ctx->rd_arena) HIP_OK(ctx, hipFree(ctx->rd_arena));
         ctx->rd_arena = nullptr; ctx->rd_cap = 0;
@@ -1112,6 +1122,15 @@ int radau_alloc(marl_ctx* ctx, RadauWork& w, const int32_t* groups_host)
     w.rhs_r = take(n); w.rhs_c = (cplx*)take(2 * n); w.out = take(8);
     w.small = (int32_t*)take((n + 1) / 2 + 1); w.groups = (int32_t*)take((n + 1) / 2 + 1); w.flags = (int32_t*)take(2);
     w.ng = ng;
+    w.nlevels = nlev;
+    w.pcr = ctx->radau_solver == 0;
+    for (int k = 0; k < 2; k++) {
+        w.Sr.L[k] = take(25 * N); w.Sr.D[k] = take(25 * N); w.Sr.U[k] = take(25 * N); w.Sr.Dinv[k] = take(25 * N); w.Sr.b[k] = take(n);
+        w.Sc.L[k] = (cplx*)take(50 * N); w.Sc.D[k] = (cplx*)take(50 * N); w.Sc.U[k] = (cplx*)take(50 * N); w.Sc.Dinv[k] = (cplx*)take(50 * N);
+        w.Sc.b[k] = (cplx*)take(2 * n);
+    }
+    w.Sr.alpha = take((size_t)nlev * 25 * N); w.Sr.gamma = take((size_t)nlev * 25 * N);
+    w.Sc.alpha = (cplx*)take((size_t)nlev * 50 * N); w.Sc.gamma = (cplx*)take((size_t)nlev * 50 * N);
     HIP_OK(ctx, hipMemcpyAsync(w.groups, g.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
     HIP_OK(ctx, hipStreamSynchronize(ctx->stream));   // g dies with this frame
     HIP_OK(ctx, hipMemsetAsync(w.J, 0, sizeof(double) * 15 * n, ctx->stream));
@@ -1119,6 +1138,48 @@ int radau_alloc(marl_ctx* ctx, RadauWork& w, const int32_t* groups_host)
 }
 
 inline unsigned blocks256(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+// factorise  mu_r I - J  and  mu_c I - J  (block PCR: 1 + ceil(log2 N) launches; or sequential block Thomas: 1 launch)
+int radau_factor(marl_ctx* ctx, RadauWork& w, double mu_r, cplx mu_c)
+{
+    const int64_t N = ctx->N;
+    if (!w.pcr) {
+        hipLaunchKernelGGL(radau::factor_kernel, dim3(2), dim3(64), 0, ctx->stream, w.J, N, mu_r, mu_c, w.Dinv_r, w.Up_r, w.Dinv_c, w.Up_c);
+        LAUNCH_OK(ctx);
+        return 0;
+    }
+    const dim3 grid((unsigned)((N + 63) / 64), 2);
+    for (int level = -1; level < w.nlevels; level++) {
+        hipLaunchKernelGGL(radau::pcr_factor_kernel, grid, dim3(64), 0, ctx->stream, w.J, N, level, mu_r, mu_c, w.Sr, w.Sc);
+        LAUNCH_OK(ctx);
+    }
+    return 0;
+}
+
+// solve in place: w.rhs_r (and, with `both`, w.rhs_c), cell-major
+int radau_solve(marl_ctx* ctx, RadauWork& w, bool both)
+{
+    const int64_t N = ctx->N, n = NF * N;
+    if (!w.pcr) {
+        hipLaunchKernelGGL(radau::solve_kernel, dim3(both ? 2 : 1), dim3(64), 0, ctx->stream, w.J, N, w.Dinv_r, w.Up_r, w.Dinv_c, w.Up_c, w.rhs_r, w.rhs_c,
+                           both ? 3 : 1);
+        LAUNCH_OK(ctx);
+        return 0;
+    }
+    const dim3 grid(blocks256(n), both ? 2 : 1);
+    // ping-pong: rhs -> b[0] -> b[1] -> ... ; the last launch (x = D^-1 b) writes back into rhs
+    const double* in_r = w.rhs_r;
+    const cplx* in_c = w.rhs_c;
+    for (int level = 0; level <= w.nlevels; level++) {
+        double* out_r = (level == w.nlevels) ? w.rhs_r : w.Sr.b[level & 1];
+        cplx* out_c = (level == w.nlevels) ? w.rhs_c : w.Sc.b[level & 1];
+        hipLaunchKernelGGL(radau::pcr_solve_kernel, grid, dim3(256), 0, ctx->stream, N, level, w.nlevels, 0, w.Sr, w.Sc, in_r, out_r, in_c, out_c);
+        LAUNCH_OK(ctx);
+        in_r = out_r;
+        in_c = out_c;
+    }
+    return 0;
+}
 
 // J = finite-difference Jacobian at (y, f0)  (num_jac; njev is the caller's)
 int radau_num_jac(marl_ctx* ctx, RadauWork& w, const double* y, const double* f0, double threshold)
@@ -1288,8 +1349,7 @@ int radau_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_st
             while (!converged) {
                 if (!have_lu) {
                     const cplx muc = {MU_COMPLEX.re / h, MU_COMPLEX.im / h};
-                    hipLaunchKernelGGL(radau::factor_kernel, dim3(2), dim3(64), 0, ctx->stream, w.J, N, MU_REAL / h, muc, w.Dinv_r, w.Up_r, w.Dinv_c, w.Up_c);
-                    LAUNCH_OK(ctx);
+                    if (int rc = radau_factor(ctx, w, MU_REAL / h, muc)) return rc;
                     st->nlu += 2;
                     have_lu = true;
                 }
@@ -1306,8 +1366,7 @@ int radau_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_st
                     st->nfev += 3;
                     hipLaunchKernelGGL(radau::newton_rhs_kernel, gn, b256, 0, ctx->stream, w.F, w.W, N, M_real, M_c, w.rhs_r, w.rhs_c, w.flags);
                     LAUNCH_OK(ctx);
-                    hipLaunchKernelGGL(radau::solve_kernel, dim3(2), dim3(64), 0, ctx->stream, w.J, N, w.Dinv_r, w.Up_r, w.Dinv_c, w.Up_c, w.rhs_r, w.rhs_c, 3);
-                    LAUNCH_OK(ctx);
+                    if (int rc = radau_solve(ctx, w, true)) return rc;
                     hipLaunchKernelGGL(radau::newton_update_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.y, w.rhs_r, w.rhs_c, w.scale, N, w.W, w.Z, w.YS, w.out);
                     LAUNCH_OK(ctx);
                     double ss;
@@ -1339,8 +1398,7 @@ int radau_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_st
             // error estimate (radau.py:466-478)
             hipLaunchKernelGGL(radau::error_rhs_kernel, gn, b256, 0, ctx->stream, w.f, w.Z, w.y, N, E3[0], E3[1], E3[2], h, w.rhs_r, w.ynew);
             LAUNCH_OK(ctx);
-            hipLaunchKernelGGL(radau::solve_kernel, dim3(1), dim3(64), 0, ctx->stream, w.J, N, w.Dinv_r, w.Up_r, w.Dinv_c, w.Up_c, w.rhs_r, w.rhs_c, 1);
-            LAUNCH_OK(ctx);
+            if (int rc = radau_solve(ctx, w, false)) return rc;
             hipLaunchKernelGGL(radau::error_norm_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.rhs_r, w.y, w.ynew, N, rtol, atol, w.err, w.yerr, w.out);
             LAUNCH_OK(ctx);
             double ss;
@@ -1352,8 +1410,7 @@ int radau_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_st
                 st->nfev++;
                 hipLaunchKernelGGL(radau::error_rhs_kernel, gn, b256, 0, ctx->stream, w.tmp, w.Z, w.y, N, E3[0], E3[1], E3[2], h, w.rhs_r, w.ynew);
                 LAUNCH_OK(ctx);
-                hipLaunchKernelGGL(radau::solve_kernel, dim3(1), dim3(64), 0, ctx->stream, w.J, N, w.Dinv_r, w.Up_r, w.Dinv_c, w.Up_c, w.rhs_r, w.rhs_c, 1);
-                LAUNCH_OK(ctx);
+                if (int rc = radau_solve(ctx, w, false)) return rc;
                 hipLaunchKernelGGL(radau::error_norm_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.rhs_r, w.y, w.ynew, N, rtol, atol, w.err, w.yerr, w.out);
                 LAUNCH_OK(ctx);
                 if (int rc = radau_read(ctx, w, &ss, nullptr)) return rc;

