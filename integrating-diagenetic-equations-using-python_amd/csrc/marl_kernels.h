@@ -618,11 +618,14 @@ __global__ void __launch_bounds__(CONTROL_THREADS) rk45_control_kernel(const dou
 // (RkDenseOutput, rk.py:560-574; w_2 = 0 because row 2 of P is zero).
 struct DenseWeights { double w[7]; };
 
-template <int BLK, int CPT, bool DENSE = false, class SB = StencilBlock<BLK, CPT>>
+// PARK (one-workgroup sweeps at 1024 threads, where the workgroup size caps a thread at 128 VGPRs): the step's first state y
+// (PARK >= 1) is not held in registers but in this thread's LDS column `pk` (pk[j * BLK], j = c*NF + f) and re-read where a
+// stage state is formed - five live doubles less across every evaluation.
+template <int BLK, int CPT, bool DENSE = false, class SB = StencilBlock<BLK, CPT>, int PARK = 0>
 __device__ __forceinline__ void dp45_attempt(SB& sb, double h,
                                              const double (&y)[CPT][NF], const double (&k1)[CPT][NF],
                                              double (&yn)[CPT][NF], double (&k7)[CPT][NF], double (&esum)[CPT][NF],
-                                             PointAux (&aux)[CPT], const DenseWeights& dw = DenseWeights{})
+                                             PointAux (&aux)[CPT], const DenseWeights& dw = DenseWeights{}, const double* pk = nullptr)
 {
     const double e1 = DENSE ? dw.w[0] : dp::E1, e3 = DENSE ? dw.w[2] : dp::E3, e4 = DENSE ? dw.w[3] : dp::E4;
     const double e5 = DENSE ? dw.w[4] : dp::E5, e6 = DENSE ? dw.w[5] : dp::E6, e7 = DENSE ? dw.w[6] : dp::E7;
@@ -631,31 +634,33 @@ __device__ __forceinline__ void dp45_attempt(SB& sb, double h,
     // sum is the left-to-right order of np.dot(K[:s].T, a[:s]) (rk.py:61-69).
     double ys[CPT][NF], k2[CPT][NF], k3[CPT][NF], k4[CPT][NF], kk[CPT][NF], s6[CPT][NF], bn[CPT][NF];
 #define MARL_CELLS _Pragma("unroll") for (int c = 0; c < CPT; c++) _Pragma("unroll") for (int f = 0; f < NF; f++)
-    MARL_CELLS ys[c][f] = y[c][f] + (k1[c][f] * dp::A21) * h;
+#define MARL_Y(c, f) (PARK >= 1 ? pk[((c) * NF + (f)) * BLK] : y[c][f])
+    MARL_CELLS ys[c][f] = MARL_Y(c, f) + (k1[c][f] * dp::A21) * h;
     sb.template eval<TR_FILL>(ys, k2, aux);
-    MARL_CELLS ys[c][f] = y[c][f] + (k1[c][f] * dp::A31 + k2[c][f] * dp::A32) * h;
+    MARL_CELLS ys[c][f] = MARL_Y(c, f) + (k1[c][f] * dp::A31 + k2[c][f] * dp::A32) * h;
     sb.template eval<TR_REUSE>(ys, k3, aux);
-    MARL_CELLS ys[c][f] = y[c][f] + (k1[c][f] * dp::A41 + k2[c][f] * dp::A42 + k3[c][f] * dp::A43) * h;
+    MARL_CELLS ys[c][f] = MARL_Y(c, f) + (k1[c][f] * dp::A41 + k2[c][f] * dp::A42 + k3[c][f] * dp::A43) * h;
     sb.template eval<TR_REUSE>(ys, k4, aux);
     MARL_CELLS {
-        ys[c][f] = y[c][f] + (k1[c][f] * dp::A51 + k2[c][f] * dp::A52 + k3[c][f] * dp::A53 + k4[c][f] * dp::A54) * h;
+        ys[c][f] = MARL_Y(c, f) + (k1[c][f] * dp::A51 + k2[c][f] * dp::A52 + k3[c][f] * dp::A53 + k4[c][f] * dp::A54) * h;
         s6[c][f] = k1[c][f] * dp::A61 + k2[c][f] * dp::A62 + k3[c][f] * dp::A63 + k4[c][f] * dp::A64;
         bn[c][f] = k1[c][f] * dp::B1 + k3[c][f] * dp::B3 + k4[c][f] * dp::B4;
         esum[c][f] = k1[c][f] * e1 + k3[c][f] * e3 + k4[c][f] * e4;
     }
     sb.template eval<TR_REUSE>(ys, kk, aux);   // K5
     MARL_CELLS {
-        ys[c][f] = y[c][f] + (s6[c][f] + kk[c][f] * dp::A65) * h;
+        ys[c][f] = MARL_Y(c, f) + (s6[c][f] + kk[c][f] * dp::A65) * h;
         bn[c][f] = bn[c][f] + kk[c][f] * dp::B5;
         esum[c][f] = esum[c][f] + kk[c][f] * e5;
     }
     sb.template eval<TR_REUSE>(ys, kk, aux);   // K6
     MARL_CELLS {
-        yn[c][f] = y[c][f] + h * (bn[c][f] + kk[c][f] * dp::B6);
+        yn[c][f] = MARL_Y(c, f) + h * (bn[c][f] + kk[c][f] * dp::B6);
         esum[c][f] = esum[c][f] + kk[c][f] * e6;
     }
     sb.template eval<TR_REUSE>(yn, k7, aux);
     MARL_CELLS esum[c][f] = esum[c][f] + k7[c][f] * e7;
+#undef MARL_Y
 #undef MARL_CELLS
 }
 
@@ -861,19 +866,26 @@ __global__ void __launch_bounds__(256) slab_copy_kernel(double* __restrict__ Y0,
 // on-chip for the whole integration; global memory is touched at entry and exit only.
 //   Y: [batch][5][N] field-major per instance (the reference's layout, one instance after another).
 // ---------------------------------------------------------------------------------------------
+// 1024-thread workgroups (16 waves: 4 per SIMD) cap a thread at 128 VGPRs, which this kernel overruns by the five doubles of one
+// state vector: there the step's first state y lives in LDS (SWEEP_PARK; dp45_attempt) instead of spilling to scratch.
+template <int BLK, int CPT>
+constexpr int SWEEP_PARK = (BLK * CPT >= 1024 && CPT == 1) ? 1 : 0;
+
 template <int BLK, int CPT, bool VD = false>
 __global__ void __launch_bounds__(BLK) rk45_sweep_kernel(double* __restrict__ Y, const DevConsts* __restrict__ consts,
                                                          Rk45Ctrl* __restrict__ ctrls, int64_t N,
                                                          double* __restrict__ Yold, double* __restrict__ Fold)
 {
     using SB = StencilBlock<BLK, CPT, false, VD>;
-    __shared__ double lds[SB::LDS_DOUBLES];
+    constexpr int PARK = SWEEP_PARK<BLK, CPT>;
+    __shared__ double lds[SB::LDS_DOUBLES + (PARK ? CPT * NF * BLK : 0)];
     __shared__ Rk45Ctrl sc;
     const DevConsts& C = consts[blockIdx.x];
     double* yg = Y + (int64_t)blockIdx.x * NF * N;
     Slab S = {N, 0, N, 0, N};
     const int64_t l0 = (int64_t)threadIdx.x * CPT;
     SB sb(lds, l0, consts + blockIdx.x);
+    double* pk = lds + SB::LDS_DOUBLES + threadIdx.x;   // PARK: this thread's column, pk[j * BLK]
     if (threadIdx.x == 0) sc = ctrls[blockIdx.x];
     __syncthreads();
     if (sc.status != ST_RUNNING) return;
@@ -883,17 +895,24 @@ __global__ void __launch_bounds__(BLK) rk45_sweep_kernel(double* __restrict__ Y,
     PointAux aux[CPT];
     load_cells<CPT, LAYOUT_FIELD_MAJOR>(yg, l0, S, C, y);
     sb.eval(y, k1, aux);  // f(t, y): RungeKutta.__init__ (first launch) or re-derived on resume
+    if constexpr (PARK) {
+#pragma unroll
+        for (int c = 0; c < CPT; c++)
+#pragma unroll
+            for (int f = 0; f < NF; f++) pk[(c * NF + f) * BLK] = y[c][f];
+    }
+#define MARL_Y(c, f) (PARK ? pk[((c) * NF + (f)) * BLK] : y[c][f])
 
     while (true) {
         const double h = sc.h_try;
-        dp45_attempt<BLK, CPT, false, SB>(sb, h, y, k1, yn, k7, esum, aux);
+        dp45_attempt<BLK, CPT, false, SB, PARK>(sb, h, y, k1, yn, k7, esum, aux, DenseWeights{}, pk);
         double q[NQ];
         monitors_init(q);
 #pragma unroll
         for (int c = 0; c < CPT; c++) {
             if (l0 + c < N) {
 #pragma unroll
-                for (int f = 0; f < NF; f++) q[0] += dp45_err2(esum[c][f], h, y[c][f], yn[c][f], rtol, atol);
+                for (int f = 0; f < NF; f++) q[0] += dp45_err2(esum[c][f], h, MARL_Y(c, f), yn[c][f], rtol, atol);
                 monitors_accumulate(q, yn[c], aux[c].U, aux[c].W);
             }
         }
@@ -909,7 +928,7 @@ __global__ void __launch_bounds__(BLK) rk45_sweep_kernel(double* __restrict__ Y,
                     if (l0 + c < N) {
 #pragma unroll
                         for (int f = 0; f < NF; f++) {
-                            Yold[(int64_t)blockIdx.x * NF * N + at<LAYOUT_FIELD_MAJOR>(f, l0 + c, N)] = y[c][f];
+                            Yold[(int64_t)blockIdx.x * NF * N + at<LAYOUT_FIELD_MAJOR>(f, l0 + c, N)] = MARL_Y(c, f);
                             Fold[(int64_t)blockIdx.x * NF * N + at<LAYOUT_FIELD_MAJOR>(f, l0 + c, N)] = k1[c][f];
                         }
                     }
@@ -918,7 +937,10 @@ __global__ void __launch_bounds__(BLK) rk45_sweep_kernel(double* __restrict__ Y,
 #pragma unroll
             for (int c = 0; c < CPT; c++)
 #pragma unroll
-                for (int f = 0; f < NF; f++) { y[c][f] = yn[c][f]; k1[c][f] = k7[c][f]; }
+                for (int f = 0; f < NF; f++) {
+                    if constexpr (PARK) pk[(c * NF + f) * BLK] = yn[c][f]; else y[c][f] = yn[c][f];
+                    k1[c][f] = k7[c][f];
+                }
         }
         __syncthreads();  // everyone has read sc before thread 0 may touch it again
         if (status != ST_RUNNING) break;
@@ -927,9 +949,10 @@ __global__ void __launch_bounds__(BLK) rk45_sweep_kernel(double* __restrict__ Y,
     for (int c = 0; c < CPT; c++) {
         if (l0 + c < N) {
 #pragma unroll
-            for (int f = 0; f < NF; f++) yg[at<LAYOUT_FIELD_MAJOR>(f, l0 + c, N)] = y[c][f];
+            for (int f = 0; f < NF; f++) yg[at<LAYOUT_FIELD_MAJOR>(f, l0 + c, N)] = MARL_Y(c, f);
         }
     }
+#undef MARL_Y
     if (threadIdx.x == 0) {
         sc.cur = 0;
         ctrls[blockIdx.x] = sc;
