@@ -146,6 +146,18 @@ int marl_slab_init_control(marl_ctx* ctx, const double* recs_dev, int64_t nrec, 
 int marl_slab_attempt(marl_ctx* ctx, double* rec_dev);         /* one fused Dormand-Prince attempt + its record */
 int marl_slab_control(marl_ctx* ctx, const double* recs_dev, int64_t nrec);
 int marl_slab_status(marl_ctx* ctx, marl_stats* stats);        /* synchronises */
+/* The same loop with the exchange INSIDE the library (no host language in the per-attempt path): the ranks' messages
+ * [record (8) | lower strip | upper strip] travel in one ncclAllGather on the context's stream.  The RCCL API is taken by
+ * dlopen from the librccl the process already has (`rccl_path`, e.g. the one PyTorch-ROCm bundles; NULL: the loader's
+ * default) - this library does not link RCCL.  Rank 0 makes the id (marl_slab_comm_id) and the host layer sends it to every
+ * rank (any transport); comm_init with world = 1 and id = NULL runs one slab with no communicator.
+ * Sequence:  comm_init -> load -> exchange(0) -> rhs0 -> monitors(NULL) -> exchange(0) -> init_control(NULL, world, ...) -> run
+ * -> store.  marl_slab_run enqueues  attempt -> reduce + pack -> all-gather -> unpack + control  `poll_interval` attempts at a
+ * time and reads the status once per batch. */
+int marl_slab_comm_id(const char* rccl_path, char id_out[128]);
+int marl_slab_comm_init(marl_ctx* ctx, const char* rccl_path, const char id[128], int rank, int world);
+int marl_slab_exchange(marl_ctx* ctx, int which);
+int marl_slab_run(marl_ctx* ctx, marl_stats* stats);           /* synchronises */
 
 #ifdef __cplusplus
 }

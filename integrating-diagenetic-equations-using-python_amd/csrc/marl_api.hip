@@ -3,6 +3,8 @@
 // entry point needs a HIP device and fails with an error text otherwise.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -41,6 +43,15 @@ struct marl_ctx {
     double* hrec = nullptr;     // pinned [batch][NQ]
     double* ddt = nullptr;      // [batch] per-instance dt
     double* hdt = nullptr;      // pinned [batch]: staging of the caller's dt array (the caller's buffer may die before the copy runs)
+    // domain decomposition: this rank's message / the gathered messages (device), and the RCCL communicator (dlopen'ed API)
+    double* dd_send = nullptr;
+    double* dd_gathered = nullptr;
+    double* dd_recs = nullptr;
+    int dd_rank = 0, dd_world = 1;
+    void* rccl_lib = nullptr;
+    void* rccl_comm = nullptr;
+    int (*rccl_allgather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*rccl_destroy)(void*) = nullptr;
     // implicit (Radau) path: one device arena + a small pinned read-back area
     double* rd_arena = nullptr;
     size_t rd_cap = 0;
@@ -233,6 +244,10 @@ void marl_ctx_destroy(marl_ctx* ctx)
     if (ctx->hctrl) (void)hipHostFree(ctx->hctrl);
     if (ctx->hrec) (void)hipHostFree(ctx->hrec);
     if (ctx->hdt) (void)hipHostFree(ctx->hdt);
+    if (ctx->rccl_comm && ctx->rccl_destroy) (void)ctx->rccl_destroy(ctx->rccl_comm);
+    if (ctx->dd_send) (void)hipFree(ctx->dd_send);
+    if (ctx->dd_gathered) (void)hipFree(ctx->dd_gathered);
+    if (ctx->dd_recs) (void)hipFree(ctx->dd_recs);
     if (ctx->rd_arena) (void)hipFree(ctx->rd_arena);
     if (ctx->rd_host) (void)hipHostFree(ctx->rd_host);
     delete ctx;
@@ -995,6 +1010,7 @@ int marl_slab_rhs0(marl_ctx* ctx)
 int marl_slab_monitors(marl_ctx* ctx, double* rec_dev)
 {
     SLAB_OK(ctx, "marl_slab_monitors")
+    if (!rec_dev) rec_dev = ctx->dd_send;   // library-side exchange: straight into this rank's message
     if (!rec_dev) return fail(ctx, -1, "marl_slab_monitors: invalid argument");
     if (int rc = launch_monitors(ctx, ctx->buf[0], LAYOUT_FIELD_MAJOR)) return rc;
     HIP_OK(ctx, hipMemcpyAsync(rec_dev, ctx->rec, sizeof(double) * NQ, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1005,6 +1021,7 @@ int marl_slab_init_control(marl_ctx* ctx, const double* recs_dev, int64_t nrec, 
                            double atol, int64_t max_attempts)
 {
     SLAB_OK(ctx, "marl_slab_init_control")
+    if (!recs_dev) recs_dev = ctx->dd_recs;   // library-side exchange: the records gathered by marl_slab_exchange
     if (!recs_dev || nrec < 1) return fail(ctx, -1, "marl_slab_init_control: invalid argument");
     if (!(first_step > 0) || !(t1 >= t0) || (t1 > t0 && first_step > t1 - t0)) return fail(ctx, -1, "rk45: `first_step` must be in (0, t1 - t0]");
     hipLaunchKernelGGL(reduce_records_kernel, dim3(1), dim3(256), 0, ctx->stream, recs_dev, nrec, ctx->rec);
@@ -1055,6 +1072,145 @@ int marl_slab_status(marl_ctx* ctx, marl_stats* stats)
 }
 
 }  // extern "C"
+// ---- domain decomposition with the exchange inside the library -------------------------------------------------------------
+// The RCCL API is taken from the librccl the process already has (PyTorch-ROCm bundles one; `rccl_path` names it) through
+// dlopen - this library does not link RCCL, single-GPU users never load it.
+namespace {
+constexpr int kNcclDouble = 8;   // ncclFloat64 (rccl.h)
+struct NcclId { char internal[128]; };   // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES 128)
+
+void* open_rccl(const char* path)
+{
+    void* lib = nullptr;
+    if (path && *path) lib = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    return lib;
+}
+
+inline int dd_msg(const marl_ctx* ctx) { return NQ + 2 * (2 * NF * ctx->halo); }
+
+int dd_buffers(marl_ctx* ctx)
+{
+    if (ctx->dd_send) return 0;
+    const size_t msg = (size_t)dd_msg(ctx);
+    HIP_OK(ctx, hipMalloc((void**)&ctx->dd_send, msg * sizeof(double)));
+    HIP_OK(ctx, hipMalloc((void**)&ctx->dd_gathered, msg * sizeof(double) * (size_t)ctx->dd_world));
+    HIP_OK(ctx, hipMalloc((void**)&ctx->dd_recs, NQ * sizeof(double) * (size_t)ctx->dd_world));
+    HIP_OK(ctx, hipMemsetAsync(ctx->dd_send, 0, msg * sizeof(double), ctx->stream));
+    return 0;
+}
+
+// all-gather of the ranks' messages (one slab: the message itself is the gathered buffer)
+int dd_allgather(marl_ctx* ctx, const double** gathered)
+{
+    if (!ctx->rccl_comm) { *gathered = ctx->dd_send; return 0; }   // one slab, no communicator
+    const int rc = ctx->rccl_allgather(ctx->dd_send, ctx->dd_gathered, (size_t)dd_msg(ctx), kNcclDouble, ctx->rccl_comm, ctx->stream);
+    if (rc != 0) return fail(ctx, -3, "ncclAllGather failed (ncclResult %d)", rc);
+    *gathered = ctx->dd_gathered;
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int marl_slab_comm_id(const char* rccl_path, char id_out[128])
+{
+    if (!id_out) return -1;
+    void* lib = open_rccl(rccl_path);
+    if (!lib) return fail(nullptr, -2, "marl_slab_comm_id: cannot load librccl (%s)", dlerror());
+    auto get_id = (int (*)(NcclId*))dlsym(lib, "ncclGetUniqueId");
+    if (!get_id) return fail(nullptr, -2, "marl_slab_comm_id: ncclGetUniqueId not found");
+    NcclId id;
+    const int rc = get_id(&id);
+    if (rc != 0) return fail(nullptr, -3, "ncclGetUniqueId failed (ncclResult %d)", rc);
+    memcpy(id_out, id.internal, 128);
+    return 0;
+}
+
+int marl_slab_comm_init(marl_ctx* ctx, const char* rccl_path, const char id[128], int rank, int world)
+{
+    SLAB_OK(ctx, "marl_slab_comm_init")
+    if (world < 1 || rank < 0 || rank >= world) return fail(ctx, -1, "marl_slab_comm_init: invalid rank / world");
+    if (ctx->dd_send) return fail(ctx, -1, "marl_slab_comm_init: already initialised");
+    ctx->dd_rank = rank;
+    ctx->dd_world = world;
+    if (world > 1 || id) {   // (world == 1 with an id: a one-rank communicator - exercises the RCCL path on one GPU)
+        if (!id) return fail(ctx, -1, "marl_slab_comm_init: a unique id is required for world > 1");
+        ctx->rccl_lib = open_rccl(rccl_path);
+        if (!ctx->rccl_lib) return fail(ctx, -2, "marl_slab_comm_init: cannot load librccl (%s)", dlerror());
+        auto init_rank = (int (*)(void**, int, NcclId, int))dlsym(ctx->rccl_lib, "ncclCommInitRank");
+        ctx->rccl_allgather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(ctx->rccl_lib, "ncclAllGather");
+        ctx->rccl_destroy = (int (*)(void*))dlsym(ctx->rccl_lib, "ncclCommDestroy");
+        if (!init_rank || !ctx->rccl_allgather || !ctx->rccl_destroy) return fail(ctx, -2, "marl_slab_comm_init: RCCL symbols not found");
+        NcclId nid;
+        memcpy(nid.internal, id, 128);
+        const int rc = init_rank(&ctx->rccl_comm, world, nid, rank);
+        if (rc != 0) { ctx->rccl_comm = nullptr; return fail(ctx, -3, "ncclCommInitRank failed (ncclResult %d)", rc); }
+    }
+    if (world > 1 && !ctx->rccl_comm) return fail(ctx, -1, "marl_slab_comm_init: no communicator for world > 1");
+    return dd_buffers(ctx);
+}
+
+// pack(which) -> all-gather -> unpack(which); the ranks' records end up in the context (marl_slab_init_control with recs NULL)
+int marl_slab_exchange(marl_ctx* ctx, int which)
+{
+    SLAB_OK(ctx, "marl_slab_exchange")
+    if (!ctx->dd_send) return fail(ctx, -1, "marl_slab_exchange: call marl_slab_comm_init first");
+    hipLaunchKernelGGL(slab_reduce_pack_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->buf[0], ctx->buf[1], ctx->buf[2], ctx->buf[3], ctx->dctrl, which,
+                       ctx->slab, ctx->halo, ctx->part, (int64_t)0, ctx->dd_send);
+    LAUNCH_OK(ctx);
+    const double* gathered;
+    if (int rc = dd_allgather(ctx, &gathered)) return rc;
+    hipLaunchKernelGGL(slab_unpack_control_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->buf[0], ctx->buf[1], ctx->buf[2], ctx->buf[3], ctx->dctrl, which,
+                       ctx->slab, ctx->halo, gathered, ctx->dd_rank, ctx->dd_world, dd_msg(ctx), 0);
+    LAUNCH_OK(ctx);
+    hipLaunchKernelGGL(slab_records_kernel, dim3(1), dim3(64), 0, ctx->stream, gathered, ctx->dd_world, dd_msg(ctx), ctx->dd_recs);
+    LAUNCH_OK(ctx);
+    return 0;
+}
+
+// The whole adaptive loop of a domain-decomposed run: per attempt  attempt kernel -> reduce + pack -> all-gather -> unpack +
+// control, enqueued `poll_interval` attempts at a time; the status is read once per batch (every rank reads the same status:
+// all decisions are computed from the same gathered records).  Before: load, exchange(0), rhs0, monitors(NULL), exchange(0),
+// init_control(NULL, world, ...).  After: store.
+int marl_slab_run(marl_ctx* ctx, marl_stats* stats)
+{
+    SLAB_OK(ctx, "marl_slab_run")
+    if (!stats) return fail(ctx, -1, "marl_slab_run: invalid argument");
+    if (!ctx->dd_send) return fail(ctx, -1, "marl_slab_run: call marl_slab_comm_init first");
+    const int v = default_rk45_variant(ctx);
+    const int64_t nb = rk45_blocks(ctx, v);
+    if (int rc = ensure_part(ctx, (size_t)std::max<int64_t>(nb, 1024))) return rc;
+    const int msg = dd_msg(ctx);
+    while (true) {
+        for (int64_t i = 0; i < ctx->poll; i++) {
+            switch (v) {
+                case 0: if (ctx->var_dphi) launch_attempt_t<256, 1, true>(ctx, nb, LAYOUT_FIELD_MAJOR); else launch_attempt_t<256, 1>(ctx, nb, LAYOUT_FIELD_MAJOR); break;
+                case 1: launch_attempt_t<256, 2>(ctx, nb, LAYOUT_FIELD_MAJOR); break;
+                case 2: launch_attempt_t<512, 1>(ctx, nb, LAYOUT_FIELD_MAJOR); break;
+                default: launch_attempt_t<128, 1>(ctx, nb, LAYOUT_FIELD_MAJOR); break;
+            }
+            LAUNCH_OK(ctx);
+            hipLaunchKernelGGL(slab_reduce_pack_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->buf[0], ctx->buf[1], ctx->buf[2], ctx->buf[3], ctx->dctrl, -1,
+                               ctx->slab, ctx->halo, ctx->part, nb, ctx->dd_send);
+            LAUNCH_OK(ctx);
+            const double* gathered;
+            if (int rc = dd_allgather(ctx, &gathered)) return rc;
+            hipLaunchKernelGGL(slab_unpack_control_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->buf[0], ctx->buf[1], ctx->buf[2], ctx->buf[3], ctx->dctrl,
+                               -1, ctx->slab, ctx->halo, gathered, ctx->dd_rank, ctx->dd_world, msg, 1);
+            LAUNCH_OK(ctx);
+        }
+        HIP_OK(ctx, hipMemcpyAsync(ctx->hctrl, ctx->dctrl, sizeof(Rk45Ctrl), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->hctrl->status != ST_RUNNING) break;
+    }
+    ctrl_to_stats(*ctx->hctrl, stats);
+    return 0;
+}
+
+}  // extern "C"
+
 // ==============================================================================================
 // Implicit path: scipy's Radau as the reference runs it by default (marlpde/parameters.py:213, jac_sparsity :150-199;
 // call site marlpde/Evolve_scenario.py:104-109).  Host = the scalar step logic of scipy/integrate/_ivp/radau.py

@@ -844,6 +844,83 @@ __global__ void __launch_bounds__(128) slab_unpack_kernel(double* __restrict__ Y
     }
 }
 
+
+// ---- the per-attempt pair of the domain-decomposed loop (marl_slab_run) --------------------------------------------------
+// After the attempt kernel: combine the slab's per-block records into ONE record and pack the strips the neighbours need, into
+// the rank's message  send = [record (8) | lower strip (2*5*halo) | upper strip].  nb = 0: keep send[0..8) (set by the caller).
+__global__ void __launch_bounds__(256) slab_reduce_pack_kernel(const double* __restrict__ Y0, const double* __restrict__ Y1,
+                                                               const double* __restrict__ F0, const double* __restrict__ F1,
+                                                               const Rk45Ctrl* __restrict__ ctrl, int which, Slab S, int halo,
+                                                               const double* __restrict__ part, int64_t nb, double* __restrict__ send)
+{
+    __shared__ double scratch[NQ * 256];
+    const int w = slab_which(which, ctrl);
+    const double* Y = w ? Y1 : Y0;
+    const double* F = w ? F1 : F0;
+    const int n = 2 * NF * halo;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int a = i / (NF * halo), f = (i / halo) % NF, j = i % halo;
+        const double* src = a ? F : Y;
+        send[NQ + i] = src[at<LAYOUT_FIELD_MAJOR>(f, S.out_lo + j, S.ld)];
+        send[NQ + n + i] = src[at<LAYOUT_FIELD_MAJOR>(f, S.out_hi - halo + j, S.ld)];
+    }
+    if (nb <= 0) return;
+    double q[NQ];
+    monitors_init(q);
+    for (int64_t b = threadIdx.x; b < nb; b += 256) {
+#pragma unroll
+        for (int j = 0; j < NQ; j++) {
+            const double o = part[b * NQ + j];
+            q[j] = (j == 0) ? q[j] + o : (j <= NQMIN ? nanmin(q[j], o) : nanmax(q[j], o));
+        }
+    }
+    block_reduce<256, NQ, NQMIN>(q, scratch);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < NQ; j++) send[j] = q[j];
+    }
+}
+
+// After the all-gather: copy the neighbours' strips out of the gathered messages into this slab's halo cells, then (do_control)
+// combine the ranks' records IN RANK ORDER and finish the attempt - every rank computes the same decision from the same numbers.
+__global__ void __launch_bounds__(256) slab_unpack_control_kernel(double* __restrict__ Y0, double* __restrict__ Y1, double* __restrict__ F0,
+                                                                  double* __restrict__ F1, Rk45Ctrl* __restrict__ ctrl, int which, Slab S, int halo,
+                                                                  const double* __restrict__ gathered, int rank, int world, int msg, int do_control)
+{
+    if (do_control && ctrl->status != ST_RUNNING) return;
+    const int w = slab_which(which, ctrl);      // read before thread 0 may flip ctrl->cur below
+    double* Y = w ? Y1 : Y0;
+    double* F = w ? F1 : F0;
+    const int n = 2 * NF * halo;
+    const double* lo = (rank > 0 && S.out_lo > 0) ? gathered + (int64_t)(rank - 1) * msg + NQ + n : nullptr;          // lower neighbour's UPPER strip
+    const double* hi = (rank < world - 1 && S.out_hi < S.n_buf) ? gathered + (int64_t)(rank + 1) * msg + NQ : nullptr;  // upper neighbour's LOWER strip
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int a = i / (NF * halo), f = (i / halo) % NF, j = i % halo;
+        double* dst = a ? F : Y;
+        if (lo) dst[at<LAYOUT_FIELD_MAJOR>(f, S.out_lo - halo + j, S.ld)] = lo[i];
+        if (hi) dst[at<LAYOUT_FIELD_MAJOR>(f, S.out_hi + j, S.ld)] = hi[i];
+    }
+    __syncthreads();
+    if (do_control && threadIdx.x == 0) {
+        double q[NQ];
+        monitors_init(q);
+        for (int r = 0; r < world; r++) {
+            const double* o = gathered + (int64_t)r * msg;
+#pragma unroll
+            for (int j = 0; j < NQ; j++) q[j] = (j == 0) ? q[j] + o[j] : (j <= NQMIN ? nanmin(q[j], o[j]) : nanmax(q[j], o[j]));
+        }
+        Rk45Ctrl c = *ctrl;
+        rk45_finish_attempt(c, q);
+        *ctrl = c;
+    }
+}
+
+// records of all ranks (stride msg) -> dense [world][8]
+__global__ void slab_records_kernel(const double* __restrict__ gathered, int world, int msg, double* __restrict__ recs)
+{
+    for (int i = threadIdx.x; i < world * NQ; i += blockDim.x) recs[i] = gathered[(int64_t)(i / NQ) * msg + (i % NQ)];
+}
+
 // owned cells of a slab <-> a dense [5][n_own] array
 __global__ void __launch_bounds__(256) slab_copy_kernel(double* __restrict__ Y0, double* __restrict__ Y1,
                                                         const Rk45Ctrl* __restrict__ ctrl, int which, Slab S,

@@ -56,6 +56,7 @@ class HipSlabEngine:
         self.n_own = end - begin
         _abi.check(self.ctx, self.lib.marl_set_stream(self.ctx, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
                    "marl_set_stream")
+        _abi.check(self.ctx, self.lib.marl_set_option(self.ctx, b"poll_interval", 32), "marl_set_option")
 
     def _call(self, name, *args):
         _abi.check(self.ctx, getattr(self.lib, name)(self.ctx, *args), name)
@@ -97,6 +98,36 @@ class HipSlabEngine:
     def status(self):
         st = _abi.MarlStats()
         self._call("marl_slab_status", C.byref(st))
+        return st
+
+    # -- the exchange inside the library (RCCL through the C ABI; no Python in the per-attempt path) ------------------
+    @staticmethod
+    def rccl_path():
+        """The librccl this process already has (PyTorch-ROCm bundles one): the library dlopens THAT one."""
+        import torch
+        p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        return p.encode() if os.path.exists(p) else None
+
+    def comm_id(self):
+        buf = C.create_string_buffer(128)
+        _abi.check(None, self.lib.marl_slab_comm_id(self.rccl_path(), buf), "marl_slab_comm_id")
+        return buf.raw
+
+    def comm_init(self, uid, rank, world):
+        self._call("marl_slab_comm_init", self.rccl_path(), uid, rank, world)
+
+    def exchange(self, which):
+        self._call("marl_slab_exchange", which)
+
+    def monitors_into_message(self):
+        self._call("marl_slab_monitors", None)
+
+    def init_control_gathered(self, nrec, t0, t1, first_step, rtol, atol, max_attempts):
+        self._call("marl_slab_init_control", None, nrec, t0, t1, first_step, rtol, atol, max_attempts)
+
+    def run(self):
+        st = _abi.MarlStats()
+        self._call("marl_slab_run", C.byref(st))
         return st
 
     def close(self):
@@ -142,8 +173,34 @@ class DomainDecomposedRK45:
         hi_src = self.gathered[self.rank + 1] if self.rank < self.world - 1 else self.send    # upper neighbour's LOWER strip
         self.recv_lo, self.recv_hi = lo_src[8 + n:], hi_src[8:8 + n]
         self.recs = e.new_tensor(8 * self.world)
-        self.transport = ("none (one slab)" if self.world == 1 else
-                          f"torch.distributed.all_gather_into_tensor, backend {dist.get_backend(group)}")
+        # Transport.  Product engine + (one slab | RCCL): the exchange and the whole per-attempt loop run inside the library
+        # (marl_slab_run: ncclAllGather on the context's stream, no Python per attempt).  Otherwise (gloo / injected test
+        # engines): the same sequence driven from here with torch.distributed collectives.
+        self.native = False
+        uid = None
+        backend = dist.get_backend(group) if dist.is_initialized() else None
+        want = os.environ.get("MARL_DD_TRANSPORT", "auto")          # auto | native | torch | rccl1 (one-rank communicator)
+        if isinstance(e, HipSlabEngine) and want != "torch" and (self.world == 1 or backend == "nccl"):
+            try:
+                if self.world > 1 or want == "rccl1":
+                    box = [e.comm_id() if self.rank == 0 else None]
+                    if self.world > 1:
+                        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                    uid = box[0]
+                e.comm_init(uid, self.rank, self.world)
+                self.native = True
+            except _abi.MarlError:
+                if want in ("native", "rccl1"):
+                    raise
+        if dist.is_initialized() and self.world > 1:   # every rank must take the same path
+            flag = e.torch.tensor([1 if self.native else 0], device=e.device if backend == "nccl" else "cpu") if isinstance(e, HipSlabEngine) else None
+            if flag is not None:
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                self.native = bool(flag.item())
+        self.transport = ("library loop, one slab (no communicator)" if self.native and uid is None else
+                          "library loop, ncclAllGather (RCCL via the C ABI)" if self.native else
+                          "none (one slab), host loop" if self.world == 1 else
+                          f"host loop, torch.distributed.all_gather_into_tensor, backend {backend}")
 
     # -- communication ---------------------------------------------------------------------------
     def _exchange(self, which):
@@ -161,6 +218,17 @@ class DomainDecomposedRK45:
         """``y_owned``: this rank's cells, tensor [5 * n_own] (field-major), advanced in place.
         Returns the marl_stats of the run (identical on every rank)."""
         e = self.engine
+        if self.native:
+            e.load(y_owned)
+            e.exchange(0)                # y halos
+            e.rhs0()
+            e.monitors_into_message()
+            e.exchange(0)                # f halos (FSAL vector) + the monitors record of y(t0)
+            e.init_control_gathered(self.world, float(t_span[0]), float(t_span[1]), float(first_step), float(rtol), float(atol),
+                                    int(max_attempts))
+            st = e.run()                 # attempt -> reduce + pack -> all-gather -> unpack + control, inside the library
+            e.store(y_owned)
+            return st
         e.load(y_owned)
         self._exchange(0)            # y halos
         e.rhs0()

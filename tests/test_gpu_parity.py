@@ -491,6 +491,33 @@ def test_domain_decomposition_slabs_on_one_gpu(torch_cuda, oracle, vd):
     assert rel_to_max(got, yref.reshape(5, N)) <= RUN_TOL
 
 
+@pytest.mark.parametrize("transport", ["native", "rccl1", "torch"])
+def test_domain_driver_one_slab_equals_single_grid(torch_cuda, monkeypatch, transport):
+    """DomainDecomposedRK45 as ONE slab on one GPU through each transport - the library loop without a communicator, the
+    library loop with a one-rank RCCL communicator (ncclCommInitRank / ncclAllGather really run), and the host loop - takes
+    the decisions of the single-grid integrator and reaches its state."""
+    torch = torch_cuda
+    from marlpde_amd.domain import DomainDecomposedRK45
+    monkeypatch.setenv("MARL_DD_TRANSPORT", transport)
+    N = 40000
+    p = scenario("default", N)
+    y = synthetic_state(p, N, amplitude=0.03)
+    dx2 = ((p["max_depth"] / p["Xstar"]) / N) ** 2
+    eq = make_model(p)
+    eq.use_stream(torch.cuda.current_stream().cuda_stream)
+    yd = torch.from_numpy(y).cuda()
+    ref = eq.integrate_rk45_device(yd.data_ptr(), (0.0, 60 * dx2), 0.5 * dx2, 1e-5, 1e-7)
+    dd = DomainDecomposedRK45(p, N, device=0)
+    assert ("library loop" in dd.transport) == (transport != "torch"), dd.transport
+    assert ("ncclAllGather" in dd.transport) == (transport == "rccl1"), dd.transport
+    own = torch.from_numpy(y.copy()).cuda()
+    st = dd.integrate(own, (0.0, 60 * dx2), 0.5 * dx2, 1e-5, 1e-7)
+    assert (st.status, st.n_accepted, st.n_rejected, st.nfev) == (ref.status, ref.n_accepted, ref.n_rejected, ref.nfev)
+    assert rel_to_max(own.cpu().numpy(), yd.cpu().numpy()) <= 1e-13
+    dd.close()
+    eq.close()
+
+
 def test_config5_full_size_decomposition_equals_single_grid(torch_cuda):
     """BASELINE config 5 at its full size (N = 2^22, RK45): the decomposition is invisible - three slabs with
     exchanged halos take the same accept/reject decisions as the single-grid integrator (itself checked against the
