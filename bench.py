@@ -110,6 +110,11 @@ def main():
                  "run `python bench.py --gpus N` (it starts the ranks itself) or torchrun --nproc-per-node N ... --gpus N")
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL / tensor sharing)
+    # stdout carries exactly ONE line, the JSON record: everything else that native libraries print there (RCCL's version
+    # banner at communicator creation, for one) is sent to stderr by pointing fd 1 at fd 2 until the record is written
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -404,7 +409,7 @@ def main():
                 extra["extras_timed_out_after_s"] = EXTRAS_DEADLINE_S
             if extra:
                 line["extra"] = extra
-            print(json.dumps(line), flush=True)
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
 
     def deadline():
         emit(timed_out=True)

@@ -529,6 +529,20 @@ static void launch_attempt_t(marl_ctx* ctx, int64_t nb, int layout)
                            ctx->buf[1], ctx->buf[2], ctx->buf[3], ctx->dconsts, ctx->slab, ctx->dctrl, ctx->part);
 }
 
+// Records of a large grid are reduced in two levels: `*nrec` per-workgroup records at ctx->part -> at most kReduceGroups
+// records behind them (same buffer, offset `*nrec`); returns where the second level reads and updates *nrec.
+constexpr int64_t kReduceGroups = 64;
+static const double* reduce_first_level(marl_ctx* ctx, int64_t* nrec)
+{
+    const int64_t nb = *nrec;
+    if (nb <= 4 * kReduceGroups) return ctx->part;
+    const int64_t chunk = (nb + kReduceGroups - 1) / kReduceGroups, groups = (nb + chunk - 1) / chunk;
+    double* out = ctx->part + nb * NQ;
+    hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)groups), dim3(256), 0, ctx->stream, ctx->part, nb, chunk, out);
+    *nrec = groups;
+    return out;
+}
+
 static int launch_attempt(marl_ctx* ctx, int v, int layout)
 {
     const int64_t nb = rk45_blocks(ctx, v);
@@ -540,7 +554,10 @@ static int launch_attempt(marl_ctx* ctx, int v, int layout)
         default: return fail(ctx, -1, "rk45 variant %d not instantiated", v);
     }
     LAUNCH_OK(ctx);
-    hipLaunchKernelGGL(rk45_control_kernel, dim3(1), dim3(CONTROL_THREADS), 0, ctx->stream, ctx->part, nb, ctx->dctrl);
+    int64_t nrec = nb;
+    const double* recs = reduce_first_level(ctx, &nrec);
+    LAUNCH_OK(ctx);
+    hipLaunchKernelGGL(rk45_control_kernel, dim3(1), dim3(CONTROL_THREADS), 0, ctx->stream, recs, nrec, ctx->dctrl);
     LAUNCH_OK(ctx);
     return 0;
 }
@@ -661,7 +678,7 @@ static int rk45_run(marl_ctx* ctx, int layout, bool small, double t0, double t1,
     const int v = small ? 0 : default_rk45_variant(ctx);
     const int sv = small ? default_sweep_variant(ctx) : -1;
     const int64_t nb = rk45_blocks(ctx, v);
-    if (int rc = ensure_part(ctx, (size_t)std::max<int64_t>(nb, 1024))) return rc;
+    if (int rc = ensure_part(ctx, (size_t)std::max<int64_t>(nb + kReduceGroups, 1024))) return rc;
     const int64_t sd = state_doubles(ctx->slab.n_buf, layout);
     // f(t0, y0) and the monitors at t0
     if (!small)
@@ -1038,7 +1055,7 @@ int marl_slab_attempt(marl_ctx* ctx, double* rec_dev)
     if (!rec_dev) return fail(ctx, -1, "marl_slab_attempt: invalid argument");
     const int v = default_rk45_variant(ctx);
     const int64_t nb = rk45_blocks(ctx, v);
-    if (int rc = ensure_part(ctx, (size_t)std::max<int64_t>(nb, 1024))) return rc;
+    if (int rc = ensure_part(ctx, (size_t)std::max<int64_t>(nb + kReduceGroups, 1024))) return rc;
     switch (v) {
         case 0: if (ctx->var_dphi) launch_attempt_t<256, 1, true>(ctx, nb, LAYOUT_FIELD_MAJOR); else launch_attempt_t<256, 1>(ctx, nb, LAYOUT_FIELD_MAJOR); break;
         case 1: launch_attempt_t<256, 2>(ctx, nb, LAYOUT_FIELD_MAJOR); break;
@@ -1046,8 +1063,11 @@ int marl_slab_attempt(marl_ctx* ctx, double* rec_dev)
         default: launch_attempt_t<128, 1>(ctx, nb, LAYOUT_FIELD_MAJOR); break;
     }
     LAUNCH_OK(ctx);
+    int64_t nrec = nb;
+    const double* recs = reduce_first_level(ctx, &nrec);
+    LAUNCH_OK(ctx);
     // one record for this rank; harmless (stale partials) when the controller is no longer running: control ignores it
-    hipLaunchKernelGGL(reduce_records_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->part, nb, rec_dev);
+    hipLaunchKernelGGL(reduce_records_kernel, dim3(1), dim3(256), 0, ctx->stream, recs, nrec, rec_dev);
     LAUNCH_OK(ctx);
     return 0;
 }
@@ -1181,7 +1201,7 @@ int marl_slab_run(marl_ctx* ctx, marl_stats* stats)
     if (!ctx->dd_send) return fail(ctx, -1, "marl_slab_run: call marl_slab_comm_init first");
     const int v = default_rk45_variant(ctx);
     const int64_t nb = rk45_blocks(ctx, v);
-    if (int rc = ensure_part(ctx, (size_t)std::max<int64_t>(nb, 1024))) return rc;
+    if (int rc = ensure_part(ctx, (size_t)std::max<int64_t>(nb + kReduceGroups, 1024))) return rc;
     const int msg = dd_msg(ctx);
     while (true) {
         for (int64_t i = 0; i < ctx->poll; i++) {
@@ -1192,8 +1212,11 @@ int marl_slab_run(marl_ctx* ctx, marl_stats* stats)
                 default: launch_attempt_t<128, 1>(ctx, nb, LAYOUT_FIELD_MAJOR); break;
             }
             LAUNCH_OK(ctx);
+            int64_t nrec = nb;
+            const double* recs = reduce_first_level(ctx, &nrec);
+            LAUNCH_OK(ctx);
             hipLaunchKernelGGL(slab_reduce_pack_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->buf[0], ctx->buf[1], ctx->buf[2], ctx->buf[3], ctx->dctrl, -1,
-                               ctx->slab, ctx->halo, ctx->part, nb, ctx->dd_send);
+                               ctx->slab, ctx->halo, recs, nrec, ctx->dd_send);
             LAUNCH_OK(ctx);
             const double* gathered;
             if (int rc = dd_allgather(ctx, &gathered)) return rc;

@@ -339,6 +339,29 @@ __global__ void __launch_bounds__(256) reduce_records_kernel(const double* __res
     }
 }
 
+// First level of a two-level reduction of MANY records (one per workgroup of a large grid): workgroup b reduces the records
+// [b * chunk, min(nrec, (b + 1) * chunk)) into out[b] - a fixed partition, so the result is reproducible.  One workgroup reading
+// thousands of records alone is latency-bound (17 000 records at N = 2^22: ~60 us); 64 workgroups take ~3 us.
+__global__ void __launch_bounds__(256) reduce_chunks_kernel(const double* __restrict__ part, int64_t nrec, int64_t chunk, double* __restrict__ out)
+{
+    __shared__ double scratch[NQ * 256];
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = (lo + chunk < nrec) ? lo + chunk : nrec;
+    double q[NQ];
+    monitors_init(q);
+    for (int64_t b = lo + threadIdx.x; b < hi; b += 256) {
+#pragma unroll
+        for (int j = 0; j < NQ; j++) {
+            const double o = part[b * NQ + j];
+            q[j] = (j == 0) ? q[j] + o : (j <= NQMIN ? nanmin(q[j], o) : nanmax(q[j], o));
+        }
+    }
+    block_reduce<256, NQ, NQMIN>(q, scratch);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < NQ; j++) out[(int64_t)blockIdx.x * NQ + j] = q[j];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Shared load / store of a thread's cells
 // ---------------------------------------------------------------------------------------------
