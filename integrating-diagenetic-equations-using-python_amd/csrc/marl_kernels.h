@@ -641,9 +641,9 @@ __global__ void __launch_bounds__(CONTROL_THREADS) rk45_control_kernel(const dou
 // (RkDenseOutput, rk.py:560-574; w_2 = 0 because row 2 of P is zero).
 struct DenseWeights { double w[7]; };
 
-// PARK (one-workgroup sweeps at 1024 threads, where the workgroup size caps a thread at 128 VGPRs): the step's first state y
-// (PARK >= 1) is not held in registers but in this thread's LDS column `pk` (pk[j * BLK], j = c*NF + f) and re-read where a
-// stage state is formed - five live doubles less across every evaluation.
+// PARK = number of fields (0..5) of the step's first state y that are NOT held in registers but in this thread's LDS column
+// `pk` (pk[(c*NF + f) * BLK], f < PARK) and re-read where a stage state is formed - up to five live doubles less across every
+// evaluation (kernels that sit just above a register cap: 128 VGPRs = 4 waves per SIMD).
 template <int BLK, int CPT, bool DENSE = false, class SB = StencilBlock<BLK, CPT>, int PARK = 0>
 __device__ __forceinline__ void dp45_attempt(SB& sb, double h,
                                              const double (&y)[CPT][NF], const double (&k1)[CPT][NF],
@@ -657,7 +657,7 @@ __device__ __forceinline__ void dp45_attempt(SB& sb, double h,
     // sum is the left-to-right order of np.dot(K[:s].T, a[:s]) (rk.py:61-69).
     double ys[CPT][NF], k2[CPT][NF], k3[CPT][NF], k4[CPT][NF], kk[CPT][NF], s6[CPT][NF], bn[CPT][NF];
 #define MARL_CELLS _Pragma("unroll") for (int c = 0; c < CPT; c++) _Pragma("unroll") for (int f = 0; f < NF; f++)
-#define MARL_Y(c, f) (PARK >= 1 ? pk[((c) * NF + (f)) * BLK] : y[c][f])
+#define MARL_Y(c, f) ((f) < PARK ? pk[((c) * NF + (f)) * BLK] : y[c][f])
     MARL_CELLS ys[c][f] = MARL_Y(c, f) + (k1[c][f] * dp::A21) * h;
     sb.template eval<TR_FILL>(ys, k2, aux);
     MARL_CELLS ys[c][f] = MARL_Y(c, f) + (k1[c][f] * dp::A31 + k2[c][f] * dp::A32) * h;
@@ -701,8 +701,17 @@ __device__ __forceinline__ double dp45_err2(double esum, double h, double y, dou
 // (y, f) from buffer `cur`, writes (y_new, f_new) into the other buffer and one reduction record per
 // block; rk45_control_kernel then accepts (flips `cur`) or rejects.  FSAL: f_new becomes K1.
 // ---------------------------------------------------------------------------------------------
+// One cell per thread in 256-thread blocks: 4 waves per SIMD (<= 128 VGPRs) with ATTEMPT_PARK fields of y parked in LDS
+// (4 blocks per CU leave 9 KB of LDS per block beside the edge buffers, tables and cache slots; three parked doubles = 6 KB suffice: 128 VGPRs, no scratch).
+#ifndef MARL_ATTEMPT_PARK
+#define MARL_ATTEMPT_PARK 3
+#endif
+template <int BLK, int CPT>
+constexpr int ATTEMPT_PARK = (BLK == 256 && CPT == 1) ? MARL_ATTEMPT_PARK : 0;
+
 template <int BLK, int CPT, int LAYOUT, bool VD = false>
-__global__ void __launch_bounds__(BLK) rk45_attempt_kernel(double* __restrict__ Y0, double* __restrict__ Y1,
+__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((BLK == 256 && CPT == 1 && MARL_ATTEMPT_PARK > 0) ? 4 : 1, 8)))
+rk45_attempt_kernel(double* __restrict__ Y0, double* __restrict__ Y1,
                                                            double* __restrict__ F0, double* __restrict__ F1,
                                                            const DevConsts* __restrict__ consts, Slab S,
                                                            const Rk45Ctrl* __restrict__ ctrl, double* __restrict__ part)
@@ -710,8 +719,9 @@ __global__ void __launch_bounds__(BLK) rk45_attempt_kernel(double* __restrict__ 
     constexpr int H = 6;
     constexpr int WIN = BLK * CPT;
     constexpr int V = WIN - 2 * H;
+    constexpr int PARK = ATTEMPT_PARK<BLK, CPT>;
     using SB = StencilBlock<BLK, CPT, true, VD>;
-    __shared__ double lds[SB::LDS_DOUBLES];
+    __shared__ double lds[SB::LDS_DOUBLES + PARK * CPT * BLK];
     if (ctrl->status != ST_RUNNING) return;
     const DevConsts& C = consts[0];
     const int cur = ctrl->cur;
@@ -735,7 +745,14 @@ __global__ void __launch_bounds__(BLK) rk45_attempt_kernel(double* __restrict__ 
         for (int f = 0; f < NF; f++) k1[c][f] = in ? fin[at<LAYOUT>(f, l, S.ld)] : 0.0;
     }
     SB sb(lds, l0 + S.goff, consts);   // (table copy + barrier inside)
-    dp45_attempt<BLK, CPT, false, SB>(sb, h, y, k1, yn, k7, esum, aux);
+    double* pk = lds + SB::LDS_DOUBLES + threadIdx.x;
+    if constexpr (PARK > 0) {
+#pragma unroll
+        for (int c = 0; c < CPT; c++)
+#pragma unroll
+            for (int f = 0; f < PARK; f++) pk[(c * NF + f) * BLK] = y[c][f];
+    }
+    dp45_attempt<BLK, CPT, false, SB, PARK>(sb, h, y, k1, yn, k7, esum, aux, DenseWeights{}, pk);
 
     double q[NQ];
     monitors_init(q);
@@ -748,7 +765,7 @@ __global__ void __launch_bounds__(BLK) rk45_attempt_kernel(double* __restrict__ 
             for (int f = 0; f < NF; f++) {
                 yout[at<LAYOUT>(f, l, S.ld)] = yn[c][f];
                 fout[at<LAYOUT>(f, l, S.ld)] = k7[c][f];
-                q[0] += dp45_err2(esum[c][f], h, y[c][f], yn[c][f], rtol, atol);
+                q[0] += dp45_err2(esum[c][f], h, f < PARK ? pk[(c * NF + f) * BLK] : y[c][f], yn[c][f], rtol, atol);
             }
             monitors_accumulate(q, yn[c], aux[c].U, aux[c].W);
         }
@@ -969,7 +986,7 @@ __global__ void __launch_bounds__(256) slab_copy_kernel(double* __restrict__ Y0,
 // 1024-thread workgroups (16 waves: 4 per SIMD) cap a thread at 128 VGPRs, which this kernel overruns by the five doubles of one
 // state vector: there the step's first state y lives in LDS (SWEEP_PARK; dp45_attempt) instead of spilling to scratch.
 template <int BLK, int CPT>
-constexpr int SWEEP_PARK = (BLK * CPT >= 1024 && CPT == 1) ? 1 : 0;
+constexpr int SWEEP_PARK = (BLK * CPT >= 1024 && CPT == 1) ? NF : 0;
 
 template <int BLK, int CPT, bool VD = false>
 __global__ void __launch_bounds__(BLK) rk45_sweep_kernel(double* __restrict__ Y, const DevConsts* __restrict__ consts,
@@ -1001,7 +1018,7 @@ __global__ void __launch_bounds__(BLK) rk45_sweep_kernel(double* __restrict__ Y,
 #pragma unroll
             for (int f = 0; f < NF; f++) pk[(c * NF + f) * BLK] = y[c][f];
     }
-#define MARL_Y(c, f) (PARK ? pk[((c) * NF + (f)) * BLK] : y[c][f])
+#define MARL_Y(c, f) ((f) < PARK ? pk[((c) * NF + (f)) * BLK] : y[c][f])
 
     while (true) {
         const double h = sc.h_try;
