@@ -987,15 +987,21 @@ __global__ void __launch_bounds__(256) slab_copy_kernel(double* __restrict__ Y0,
 // on-chip for the whole integration; global memory is touched at entry and exit only.
 //   Y: [batch][5][N] field-major per instance (the reference's layout, one instance after another).
 // ---------------------------------------------------------------------------------------------
-// 1024-thread workgroups (16 waves: 4 per SIMD) cap a thread at 128 VGPRs, which this kernel overruns by the five doubles of one
-// state vector: there the step's first state y lives in LDS (SWEEP_PARK; dp45_attempt) instead of spilling to scratch.
+// 1024-thread workgroups (16 waves: 4 per SIMD) cap a thread at 128 VGPRs, which this kernel overruns (38 spilled VGPRs, 156 B
+// of scratch per lane).  Parking the step's first state y in LDS (SWEEP_PARK; dp45_attempt) brings that to 33 - and changes
+// nothing measurable (1.271e10 against 1.278e10): the spill code sits outside the stage loop, 16 scratch operations per attempt
+// against ~2000 VALU instructions per wave.  What bounds this kernel is in DESIGN.md 5 (SQ counters); parking is compiled out.
+#ifndef MARL_SWEEP_PARK
+#define MARL_SWEEP_PARK 0
+#endif
 template <int BLK, int CPT>
-constexpr int SWEEP_PARK = (BLK * CPT >= 1024 && CPT == 1) ? NF : 0;
-// One-cell-per-thread sweeps reuse transcendentals through the wide (6th-order) expansions: on a 1024-cell grid a stage moves
-// Phi by ~1e-4 relative, outside the 3rd-order range but 20x inside the 6th-order one, and the centre is renewed only every
-// few steps (TR_AUTO) - the state, the stage vectors AND the centre never leave the chip.
+constexpr int SWEEP_PARK = (MARL_SWEEP_PARK != 0 && BLK * CPT >= 1024 && CPT == 1) ? NF : 0;
+// Transcendental reuse in one-workgroup sweeps (wide 6th-order tier of the expansions, centre carried from attempt to attempt)
+// is compiled out: measured on BASELINE config 3 (4096 x N = 1024) it saves 5 % of the VALU instructions only - inside the
+// dissolution zone the solute concentrations move ~1 % per step at this resolution (dt ~ dx^2, rates ~5e4), far outside any
+// short expansion - and costs 8 more spilled VGPRs: 1.25e10 against 1.27e10 (profiles/r02_lab_sweep_experiments.log).
 #ifndef MARL_SWEEP_REUSE
-#define MARL_SWEEP_REUSE 1
+#define MARL_SWEEP_REUSE 0
 #endif
 template <int CPT>
 constexpr bool SWEEP_REUSE = (CPT == 1) && (MARL_SWEEP_REUSE != 0);
