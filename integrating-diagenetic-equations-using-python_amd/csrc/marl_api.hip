@@ -374,10 +374,10 @@ static void record_to_events(const double* r, double* g)
 
 // ---- fused RK4 variants ------------------------------------------------------------------------
 struct Rk4Variant { int blk, cpt, nsteps; };
-static const Rk4Variant kRk4Variants[] = {
-    {256, 1, 1}, {256, 1, 2}, {256, 2, 1}, {256, 2, 2}, {128, 1, 4}, {128, 1, 8}, {256, 2, 4}, {512, 1, 1}, {256, 4, 1}, {128, 1, 1},
-    {256, 1, 4}, {256, 1, 8}, {256, 1, 16},
-};
+// One shape ships: 256-thread blocks, one cell per thread (4 waves per SIMD), at 1 / 2 / 4 / 8 / 16 steps per launch - the default
+// depth depends on the grid size, the shallower ones also serve as the remainder chain.  (Other block shapes and cells per thread
+// were measured in round 1 and live in tools/rk4_lab.hip only.)
+static const Rk4Variant kRk4Variants[] = {{256, 1, 1}, {256, 1, 2}, {256, 1, 4}, {256, 1, 8}, {256, 1, 16}};
 constexpr int kNumRk4Variants = sizeof(kRk4Variants) / sizeof(kRk4Variants[0]);
 
 template <int BLK, int CPT, int NSTEPS, bool VD = false>
@@ -394,29 +394,20 @@ static void launch_rk4_t(marl_ctx* ctx, const double* yin, double* yout, int lay
 
 // The kernel sets instantiated with the time-varying porosity diffusion coefficient (dPhi_variable): one
 // one-cell-per-thread shape per integrator - the option is a model variant, not a tuning surface.
-constexpr int kVdRk4Variant = 10;   // {256, 1, 4}
+constexpr int kVdRk4Variant = 2;    // {256, 1, 4}
 constexpr int kVdRk45Variant = 0;   // {256, 1}
 
 // nsteps: steps fused in this launch - the variant's own depth, or a smaller instantiated one for the remainder
 static int launch_rk4(marl_ctx* ctx, int v, int nsteps, const double* yin, double* yout, int layout, double dt)
 {
-    const Rk4Variant& rv = kRk4Variants[v];
-    const int key = rv.blk * 1000 + rv.cpt * 100 + nsteps;
-    switch (key) {
-        case 256101: if (ctx->var_dphi) launch_rk4_t<256, 1, 1, true>(ctx, yin, yout, layout, dt); else launch_rk4_t<256, 1, 1>(ctx, yin, yout, layout, dt); break;
-        case 256102: launch_rk4_t<256, 1, 2>(ctx, yin, yout, layout, dt); break;
-        case 256104: if (ctx->var_dphi) launch_rk4_t<256, 1, 4, true>(ctx, yin, yout, layout, dt); else launch_rk4_t<256, 1, 4>(ctx, yin, yout, layout, dt); break;
-        case 256108: launch_rk4_t<256, 1, 8>(ctx, yin, yout, layout, dt); break;
-        case 256116: launch_rk4_t<256, 1, 16>(ctx, yin, yout, layout, dt); break;
-        case 256201: launch_rk4_t<256, 2, 1>(ctx, yin, yout, layout, dt); break;
-        case 256202: launch_rk4_t<256, 2, 2>(ctx, yin, yout, layout, dt); break;
-        case 256204: launch_rk4_t<256, 2, 4>(ctx, yin, yout, layout, dt); break;
-        case 128101: launch_rk4_t<128, 1, 1>(ctx, yin, yout, layout, dt); break;
-        case 128104: launch_rk4_t<128, 1, 4>(ctx, yin, yout, layout, dt); break;
-        case 128108: launch_rk4_t<128, 1, 8>(ctx, yin, yout, layout, dt); break;
-        case 512101: launch_rk4_t<512, 1, 1>(ctx, yin, yout, layout, dt); break;
-        case 256401: launch_rk4_t<256, 4, 1>(ctx, yin, yout, layout, dt); break;
-        default: return fail(ctx, -1, "rk4 variant %d not instantiated", v);
+    (void)v;
+    switch (nsteps) {
+        case 1: if (ctx->var_dphi) launch_rk4_t<256, 1, 1, true>(ctx, yin, yout, layout, dt); else launch_rk4_t<256, 1, 1>(ctx, yin, yout, layout, dt); break;
+        case 2: launch_rk4_t<256, 1, 2>(ctx, yin, yout, layout, dt); break;
+        case 4: if (ctx->var_dphi) launch_rk4_t<256, 1, 4, true>(ctx, yin, yout, layout, dt); else launch_rk4_t<256, 1, 4>(ctx, yin, yout, layout, dt); break;
+        case 8: launch_rk4_t<256, 1, 8>(ctx, yin, yout, layout, dt); break;
+        case 16: launch_rk4_t<256, 1, 16>(ctx, yin, yout, layout, dt); break;
+        default: return fail(ctx, -1, "rk4: %d steps per launch not instantiated", nsteps);
     }
     LAUNCH_OK(ctx);
     return 0;
@@ -429,7 +420,7 @@ static int default_rk4_variant(const marl_ctx* ctx)
     const int64_t n = ctx->slab.out_hi - ctx->slab.out_lo;
     // 256-thread blocks; the smaller the grid, the more the launch boundary matters against the recomputed halo:
     // 16 / 8 / 4 steps per launch (tools/variant_sweep.sh)
-    return n <= 98304 ? 12 : (n <= 262144 ? 11 : 10);
+    return n <= 98304 ? 4 : (n <= 262144 ? 3 : 2);
 }
 
 // y (device, `layout`) advanced in place; `tmp` is a second buffer of the same size
@@ -445,8 +436,8 @@ static int rk4_run(marl_ctx* ctx, double* y, double* tmp, int layout, double dt,
         std::swap(a, b);
         left -= per;
     }
-    // remainder: the {256, 1, *} family is instantiated at every power of two below its depth; others step singly
-    const bool family = kRk4Variants[v].blk == 256 && kRk4Variants[v].cpt == 1 && !ctx->var_dphi;
+    // remainder: every power of two below the depth is instantiated (the dPhi_variable set: depths 4 and 1 only)
+    const bool family = !ctx->var_dphi;
     for (int chunk = per / 2; chunk >= 1 && left > 0; chunk /= 2) {
         const int c = family ? chunk : 1;
         while (left >= c) {
@@ -462,46 +453,33 @@ static int rk4_run(marl_ctx* ctx, double* y, double* tmp, int layout, double dt,
 
 // ---- sweep variants ----------------------------------------------------------------------------
 struct SweepVariant { int blk, cpt; };
-static const SweepVariant kSweepVariants[] = {{256, 4}, {512, 2}, {1024, 1}, {256, 1}, {128, 2}, {64, 4}, {256, 2}, {128, 4}, {512, 1}};
+// one cell per thread; the smallest window that holds the grid is taken
+static const SweepVariant kSweepVariants[] = {{256, 1}, {512, 1}, {1024, 1}};
 constexpr int kNumSweepVariants = sizeof(kSweepVariants) / sizeof(kSweepVariants[0]);
 
 static int default_sweep_variant(marl_ctx* ctx)
 {
-    if (!ctx->var_dphi && ctx->sweep_variant >= 0 && ctx->sweep_variant < kNumSweepVariants) {
-        const SweepVariant& sv = kSweepVariants[ctx->sweep_variant];
-        if ((int64_t)sv.blk * sv.cpt >= ctx->N) return (int)ctx->sweep_variant;
-    }
-    const int order[] = {3, 4, 5, 8, 6, 7, 2, 1, 0};  // smallest window first; among equal windows the measured-fastest first (one cell per thread)
-    int best = -1;
-    int64_t best_win = 0;
-    for (int i : order) {
-        const int64_t win = (int64_t)kSweepVariants[i].blk * kSweepVariants[i].cpt;
-        if (ctx->var_dphi && kSweepVariants[i].cpt != 1) continue;   // VD kernels: the one-cell-per-thread shapes only
-        if (win >= ctx->N && (best < 0 || win < best_win)) { best = i; best_win = win; }
-    }
-    return best;
+    if (ctx->sweep_variant >= 0 && ctx->sweep_variant < kNumSweepVariants && (int64_t)kSweepVariants[ctx->sweep_variant].blk >= ctx->N)
+        return (int)ctx->sweep_variant;
+    for (int i = 0; i < kNumSweepVariants; i++)
+        if ((int64_t)kSweepVariants[i].blk * kSweepVariants[i].cpt >= ctx->N) return i;
+    return -1;
 }
 
 #define SWEEP_DISPATCH(KERNEL, ...)                                                                           \
     switch (v) {                                                                                              \
-        case 0: hipLaunchKernelGGL((KERNEL<256, 4>), grid, dim3(256), 0, ctx->stream, __VA_ARGS__); break;    \
-        case 1: hipLaunchKernelGGL((KERNEL<512, 2>), grid, dim3(512), 0, ctx->stream, __VA_ARGS__); break;    \
+        case 0: if (ctx->var_dphi) hipLaunchKernelGGL((KERNEL<256, 1, true>), grid, dim3(256), 0, ctx->stream, __VA_ARGS__); \
+                else hipLaunchKernelGGL((KERNEL<256, 1>), grid, dim3(256), 0, ctx->stream, __VA_ARGS__); break;    \
+        case 1: if (ctx->var_dphi) hipLaunchKernelGGL((KERNEL<512, 1, true>), grid, dim3(512), 0, ctx->stream, __VA_ARGS__); \
+                else hipLaunchKernelGGL((KERNEL<512, 1>), grid, dim3(512), 0, ctx->stream, __VA_ARGS__); break;    \
         case 2: if (ctx->var_dphi) hipLaunchKernelGGL((KERNEL<1024, 1, true>), grid, dim3(1024), 0, ctx->stream, __VA_ARGS__); \
                 else hipLaunchKernelGGL((KERNEL<1024, 1>), grid, dim3(1024), 0, ctx->stream, __VA_ARGS__); break;  \
-        case 3: if (ctx->var_dphi) hipLaunchKernelGGL((KERNEL<256, 1, true>), grid, dim3(256), 0, ctx->stream, __VA_ARGS__); \
-                else hipLaunchKernelGGL((KERNEL<256, 1>), grid, dim3(256), 0, ctx->stream, __VA_ARGS__); break;    \
-        case 4: hipLaunchKernelGGL((KERNEL<128, 2>), grid, dim3(128), 0, ctx->stream, __VA_ARGS__); break;    \
-        case 5: hipLaunchKernelGGL((KERNEL<64, 4>), grid, dim3(64), 0, ctx->stream, __VA_ARGS__); break;      \
-        case 6: hipLaunchKernelGGL((KERNEL<256, 2>), grid, dim3(256), 0, ctx->stream, __VA_ARGS__); break;    \
-        case 7: hipLaunchKernelGGL((KERNEL<128, 4>), grid, dim3(128), 0, ctx->stream, __VA_ARGS__); break;    \
-        case 8: if (ctx->var_dphi) hipLaunchKernelGGL((KERNEL<512, 1, true>), grid, dim3(512), 0, ctx->stream, __VA_ARGS__); \
-                else hipLaunchKernelGGL((KERNEL<512, 1>), grid, dim3(512), 0, ctx->stream, __VA_ARGS__); break;    \
         default: return fail(ctx, -1, "sweep variant %d not instantiated", v);                                \
     }
 
 // ---- fused RK45 variants -----------------------------------------------------------------------
 struct Rk45Variant { int blk, cpt; };
-static const Rk45Variant kRk45Variants[] = {{256, 1}, {256, 2}, {512, 1}, {128, 1}};
+static const Rk45Variant kRk45Variants[] = {{256, 1}};   // (other shapes were measured in round 1; none faster)
 constexpr int kNumRk45Variants = sizeof(kRk45Variants) / sizeof(kRk45Variants[0]);
 
 static int default_rk45_variant(const marl_ctx* ctx)
@@ -548,9 +526,6 @@ static int launch_attempt(marl_ctx* ctx, int v, int layout)
     const int64_t nb = rk45_blocks(ctx, v);
     switch (v) {
         case 0: if (ctx->var_dphi) launch_attempt_t<256, 1, true>(ctx, nb, layout); else launch_attempt_t<256, 1>(ctx, nb, layout); break;
-        case 1: launch_attempt_t<256, 2>(ctx, nb, layout); break;
-        case 2: launch_attempt_t<512, 1>(ctx, nb, layout); break;
-        case 3: launch_attempt_t<128, 1>(ctx, nb, layout); break;
         default: return fail(ctx, -1, "rk45 variant %d not instantiated", v);
     }
     LAUNCH_OK(ctx);
@@ -601,9 +576,6 @@ static int dense_eval(marl_ctx* ctx, int v, int layout, bool small, const Rk45Ct
     const int64_t nb = rk45_blocks(ctx, v);
     switch (v) {
         case 0: if (ctx->var_dphi) launch_dense_t<256, 1, true>(ctx, nb, layout, yold, fold, c.h_prev, dw, yout); else launch_dense_t<256, 1>(ctx, nb, layout, yold, fold, c.h_prev, dw, yout); break;
-        case 1: launch_dense_t<256, 2>(ctx, nb, layout, yold, fold, c.h_prev, dw, yout); break;
-        case 2: launch_dense_t<512, 1>(ctx, nb, layout, yold, fold, c.h_prev, dw, yout); break;
-        case 3: launch_dense_t<128, 1>(ctx, nb, layout, yold, fold, c.h_prev, dw, yout); break;
         default: return fail(ctx, -1, "rk45 variant %d not instantiated", v);
     }
     LAUNCH_OK(ctx);
@@ -1056,12 +1028,7 @@ int marl_slab_attempt(marl_ctx* ctx, double* rec_dev)
     const int v = default_rk45_variant(ctx);
     const int64_t nb = rk45_blocks(ctx, v);
     if (int rc = ensure_part(ctx, (size_t)std::max<int64_t>(nb + kReduceGroups, 1024))) return rc;
-    switch (v) {
-        case 0: if (ctx->var_dphi) launch_attempt_t<256, 1, true>(ctx, nb, LAYOUT_FIELD_MAJOR); else launch_attempt_t<256, 1>(ctx, nb, LAYOUT_FIELD_MAJOR); break;
-        case 1: launch_attempt_t<256, 2>(ctx, nb, LAYOUT_FIELD_MAJOR); break;
-        case 2: launch_attempt_t<512, 1>(ctx, nb, LAYOUT_FIELD_MAJOR); break;
-        default: launch_attempt_t<128, 1>(ctx, nb, LAYOUT_FIELD_MAJOR); break;
-    }
+    if (ctx->var_dphi) launch_attempt_t<256, 1, true>(ctx, nb, LAYOUT_FIELD_MAJOR); else launch_attempt_t<256, 1>(ctx, nb, LAYOUT_FIELD_MAJOR);
     LAUNCH_OK(ctx);
     int64_t nrec = nb;
     const double* recs = reduce_first_level(ctx, &nrec);
@@ -1205,12 +1172,7 @@ int marl_slab_run(marl_ctx* ctx, marl_stats* stats)
     const int msg = dd_msg(ctx);
     while (true) {
         for (int64_t i = 0; i < ctx->poll; i++) {
-            switch (v) {
-                case 0: if (ctx->var_dphi) launch_attempt_t<256, 1, true>(ctx, nb, LAYOUT_FIELD_MAJOR); else launch_attempt_t<256, 1>(ctx, nb, LAYOUT_FIELD_MAJOR); break;
-                case 1: launch_attempt_t<256, 2>(ctx, nb, LAYOUT_FIELD_MAJOR); break;
-                case 2: launch_attempt_t<512, 1>(ctx, nb, LAYOUT_FIELD_MAJOR); break;
-                default: launch_attempt_t<128, 1>(ctx, nb, LAYOUT_FIELD_MAJOR); break;
-            }
+            if (ctx->var_dphi) launch_attempt_t<256, 1, true>(ctx, nb, LAYOUT_FIELD_MAJOR); else launch_attempt_t<256, 1>(ctx, nb, LAYOUT_FIELD_MAJOR);
             LAUNCH_OK(ctx);
             int64_t nrec = nb;
             const double* recs = reduce_first_level(ctx, &nrec);

@@ -105,13 +105,13 @@ def test_rhs_device_layouts_against_oracle(torch_cuda, oracle, N):
     eq.close()
 
 
-RK4_VARIANT_DEPTH = (1, 2, 1, 2, 4, 8, 4, 1, 1, 1, 4, 8, 16)   # steps per launch of kRk4Variants (marl_api.hip)
+RK4_VARIANT_DEPTH = (1, 2, 4, 8, 16)   # steps per launch of kRk4Variants (marl_api.hip)
 
 
 @pytest.mark.parametrize("layout", [0, 1])
-@pytest.mark.parametrize("variant", range(13))
+@pytest.mark.parametrize("variant", range(5))
 def test_rk4_fused_variants_against_oracle(torch_cuda, oracle, variant, layout):
-    """Every fused-RK4 instantiation (block size, cells/thread, steps/launch) on a grid that is not a
+    """Every shipped fused-RK4 instantiation (1 / 2 / 4 / 8 / 16 steps per launch, both layouts) on a grid that is not a
     multiple of any tile, incl. a step count that is not a multiple of the fused depth."""
     torch = torch_cuda
     from marlpde_amd._abi import LAYOUT_FIELD_MAJOR
@@ -197,10 +197,10 @@ def test_rk45_reproduces_scipy_trajectory(traj):
 
 
 @pytest.mark.parametrize("layout", [0, 1])
-@pytest.mark.parametrize("variant", range(4))
-def test_rk45_fused_large_grid_against_oracle(torch_cuda, oracle, variant, layout):
+@pytest.mark.parametrize("N", [5003, 777])
+def test_rk45_fused_large_grid_against_oracle(torch_cuda, oracle, N, layout):
     torch = torch_cuda
-    N = 5003
+    variant = 0
     p = scenario("A", N)
     eq = make_model(p)
     eq.use_stream(torch.cuda.current_stream().cuda_stream)
@@ -361,7 +361,7 @@ def test_full_size_rk4_against_oracle_and_layout_agreement(torch_cuda, oracle):
     """BASELINE headline size N = 2^20: a few fused steps against the oracle, and the two device layouts /
     two kernel variants against each other."""
     torch = torch_cuda
-    N, nsteps = 1 << 20, 4
+    N, nsteps = 1 << 20, 8
     p = scenario("default", N)
     eq = make_model(p)
     eq.use_stream(torch.cuda.current_stream().cuda_stream)
@@ -369,7 +369,7 @@ def test_full_size_rk4_against_oracle_and_layout_agreement(torch_cuda, oracle):
     dt = 0.25 * (eq.Depths.length / N) ** 2
     ref = oracle.rk4(oracle.params_from_model(eq), N, y, dt, nsteps, omp=True)
     results = []
-    for variant, layout in ((2, 1), (2, 0), (0, 1), (6, 1)):
+    for variant, layout in ((2, 1), (2, 0), (0, 1), (3, 1)):   # 4 steps per launch (the default here), 1 and 8
         eq.set_option("rk4_variant", variant)
         yd = torch.from_numpy(y).cuda()
         buf = yd
