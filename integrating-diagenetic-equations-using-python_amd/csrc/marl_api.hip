@@ -1219,7 +1219,6 @@ struct RadauWork {
     radau::PcrSystem<cplx> Sc{};
     int nlevels = 0;
     bool pcr = true;
-    bool fused = false;   // N <= radau::SMALL_N: level loops inside one workgroup, element-wise kernels folded in
 };
 
 int radau_alloc(marl_ctx* ctx, RadauWork& w, const int32_t* groups_host)
@@ -1265,8 +1264,7 @@ int radau_alloc(marl_ctx* ctx, RadauWork& w, const int32_t* groups_host)
     w.small = (int32_t*)take((n + 1) / 2 + 1); w.groups = (int32_t*)take((n + 1) / 2 + 1); w.flags = (int32_t*)take(2);
     w.ng = ng;
     w.nlevels = nlev;
-    w.pcr = ctx->radau_solver != 1;
-    w.fused = w.pcr && N <= radau::SMALL_N && ctx->radau_solver == 0;   // radau_solver 2: PCR with one launch per level at any N
+    w.pcr = ctx->radau_solver == 0;
     for (int k = 0; k < 2; k++) {
         w.Sr.L[k] = take(25 * N); w.Sr.D[k] = take(25 * N); w.Sr.U[k] = take(25 * N); w.Sr.Dinv[k] = take(25 * N); w.Sr.b[k] = take(n);
         w.Sc.L[k] = (cplx*)take(50 * N); w.Sc.D[k] = (cplx*)take(50 * N); w.Sc.U[k] = (cplx*)take(50 * N); w.Sc.Dinv[k] = (cplx*)take(50 * N);
@@ -1288,11 +1286,6 @@ int radau_factor(marl_ctx* ctx, RadauWork& w, double mu_r, cplx mu_c)
     const int64_t N = ctx->N;
     if (!w.pcr) {
         hipLaunchKernelGGL(radau::factor_kernel, dim3(2), dim3(64), 0, ctx->stream, w.J, N, mu_r, mu_c, w.Dinv_r, w.Up_r, w.Dinv_c, w.Up_c);
-        LAUNCH_OK(ctx);
-        return 0;
-    }
-    if (w.fused) {
-        hipLaunchKernelGGL(radau::pcr_factor_small_kernel, dim3(2), dim3(256), 0, ctx->stream, w.J, N, w.nlevels, mu_r, mu_c, w.Sr, w.Sc);
         LAUNCH_OK(ctx);
         return 0;
     }
@@ -1346,24 +1339,6 @@ int radau_num_jac(marl_ctx* ctx, RadauWork& w, const double* y, const double* f0
     if (int rc = launch_rhs(ctx, w.YP, w.FN, LAYOUT_FIELD_MAJOR, w.ng)) return rc;
     hipLaunchKernelGGL(radau::fd_finish_kernel, dim3(blocks256(n)), dim3(256), 0, ctx->stream, f0, w.FN, w.groups, N, w.fac, w.h, w.maxdiff, w.scl, w.small,
                        w.hnew, w.Jraw, w.J);
-    LAUNCH_OK(ctx);
-    return 0;
-}
-
-// error = solve(LU_real, fvec + Z^T E / h); y_new, err, y + err; sum of (err / scale)^2 -> w.out[0]   (radau.py:466-478)
-int radau_error_estimate(marl_ctx* ctx, RadauWork& w, const double* fvec, const double (&E3)[3], double h, double rtol, double atol)
-{
-    const int64_t N = ctx->N, n = NF * N;
-    if (w.fused) {
-        hipLaunchKernelGGL(radau::error_small_kernel, dim3(1), dim3(radau::SMALL_THREADS), 0, ctx->stream, fvec, w.Z, w.y, N, w.nlevels, E3[0], E3[1], E3[2], h,
-                           rtol, atol, w.Sr, w.ynew, w.err, w.yerr, w.out);
-        LAUNCH_OK(ctx);
-        return 0;
-    }
-    hipLaunchKernelGGL(radau::error_rhs_kernel, dim3(blocks256(n)), dim3(256), 0, ctx->stream, fvec, w.Z, w.y, N, E3[0], E3[1], E3[2], h, w.rhs_r, w.ynew);
-    LAUNCH_OK(ctx);
-    if (int rc = radau_solve(ctx, w, false)) return rc;
-    hipLaunchKernelGGL(radau::error_norm_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.rhs_r, w.y, w.ynew, N, rtol, atol, w.err, w.yerr, w.out);
     LAUNCH_OK(ctx);
     return 0;
 }
@@ -1530,17 +1505,11 @@ int radau_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_st
                 for (k = 0; k < NEWTON_MAXITER; k++) {
                     if (int rc = launch_rhs(ctx, w.YS, w.F, LAYOUT_FIELD_MAJOR, 3)) return rc;
                     st->nfev += 3;
-                    if (w.fused) {
-                        hipLaunchKernelGGL(radau::newton_small_kernel, dim3(1), dim3(radau::SMALL_THREADS), 0, ctx->stream, w.F, w.y, w.scale, N, w.nlevels,
-                                           M_real, M_c, w.Sr, w.Sc, w.W, w.Z, w.YS, w.out, w.flags);
-                        LAUNCH_OK(ctx);
-                    } else {
-                        hipLaunchKernelGGL(radau::newton_rhs_kernel, gn, b256, 0, ctx->stream, w.F, w.W, N, M_real, M_c, w.rhs_r, w.rhs_c, w.flags);
-                        LAUNCH_OK(ctx);
-                        if (int rc = radau_solve(ctx, w, true)) return rc;
-                        hipLaunchKernelGGL(radau::newton_update_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.y, w.rhs_r, w.rhs_c, w.scale, N, w.W, w.Z, w.YS, w.out);
-                        LAUNCH_OK(ctx);
-                    }
+                    hipLaunchKernelGGL(radau::newton_rhs_kernel, gn, b256, 0, ctx->stream, w.F, w.W, N, M_real, M_c, w.rhs_r, w.rhs_c, w.flags);
+                    LAUNCH_OK(ctx);
+                    if (int rc = radau_solve(ctx, w, true)) return rc;
+                    hipLaunchKernelGGL(radau::newton_update_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.y, w.rhs_r, w.rhs_c, w.scale, N, w.W, w.Z, w.YS, w.out);
+                    LAUNCH_OK(ctx);
                     double ss;
                     int nonfinite;
                     if (int rc = radau_read(ctx, w, &ss, &nonfinite)) return rc;
@@ -1568,7 +1537,11 @@ int radau_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_st
                 continue;
             }
             // error estimate (radau.py:466-478)
-            if (int rc = radau_error_estimate(ctx, w, w.f, E3, h, rtol, atol)) return rc;
+            hipLaunchKernelGGL(radau::error_rhs_kernel, gn, b256, 0, ctx->stream, w.f, w.Z, w.y, N, E3[0], E3[1], E3[2], h, w.rhs_r, w.ynew);
+            LAUNCH_OK(ctx);
+            if (int rc = radau_solve(ctx, w, false)) return rc;
+            hipLaunchKernelGGL(radau::error_norm_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.rhs_r, w.y, w.ynew, N, rtol, atol, w.err, w.yerr, w.out);
+            LAUNCH_OK(ctx);
             double ss;
             if (int rc = radau_read(ctx, w, &ss, nullptr)) return rc;
             error_norm = std::sqrt(ss) / std::sqrt((double)n);
@@ -1576,7 +1549,11 @@ int radau_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_st
             if (rejected && error_norm > 1) {
                 if (int rc = launch_rhs(ctx, w.yerr, w.tmp, LAYOUT_FIELD_MAJOR)) return rc;   // fun(t, y + error)
                 st->nfev++;
-                if (int rc = radau_error_estimate(ctx, w, w.tmp, E3, h, rtol, atol)) return rc;
+                hipLaunchKernelGGL(radau::error_rhs_kernel, gn, b256, 0, ctx->stream, w.tmp, w.Z, w.y, N, E3[0], E3[1], E3[2], h, w.rhs_r, w.ynew);
+                LAUNCH_OK(ctx);
+                if (int rc = radau_solve(ctx, w, false)) return rc;
+                hipLaunchKernelGGL(radau::error_norm_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.rhs_r, w.y, w.ynew, N, rtol, atol, w.err, w.yerr, w.out);
+                LAUNCH_OK(ctx);
                 if (int rc = radau_read(ctx, w, &ss, nullptr)) return rc;
                 error_norm = std::sqrt(ss) / std::sqrt((double)n);
             }

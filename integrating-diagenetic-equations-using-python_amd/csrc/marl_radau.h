@@ -502,150 +502,6 @@ __global__ void __launch_bounds__(256) pcr_solve_kernel(int64_t N, int level, in
     else pcr_solve_row<cplx>(N, kk, level, nlevels, Sc, bin_c, bout_c);
 }
 
-// ---- small grids (N <= SMALL_N): the level loops INSIDE one workgroup -------------------------------------------------------------
-// At the reference's own size (N = 200) a launch per PCR level makes the run launch-bound: ~13 launches per Newton iteration.  Below
-// SMALL_N cells one workgroup walks the levels itself (a barrier between levels; right-hand sides in LDS), and the element-wise
-// kernels around a solve are folded in: a Newton iteration is the batched RHS launch + ONE launch, an error estimate ONE launch.
-constexpr int SMALL_N = 512;
-constexpr int SMALL_THREADS = 512;   // waves 0-3: real system, waves 4-7: complex system
-
-// factorisation: workgroup 0 real system, workgroup 1 complex system; 256 threads (the whole register file per lane)
-__global__ void __launch_bounds__(256) pcr_factor_small_kernel(const double* __restrict__ J, int64_t N, int nlevels, double mu_r, cplx mu_c,
-                                                               PcrSystem<double> Sr, PcrSystem<cplx> Sc)
-{
-    for (int level = -1; level < nlevels; level++) {
-        for (int64_t i = threadIdx.x; i < N; i += 256) {
-            if (blockIdx.x == 0) {
-                if (level < 0) pcr_init_cell<double>(J, N, i, mu_r, Sr);
-                else pcr_level_cell<double>(N, i, level, (int64_t)1 << level, Sr, 0.0);
-            } else {
-                if (level < 0) pcr_init_cell<cplx>(J, N, i, mu_c, Sc);
-                else pcr_level_cell<cplx>(N, i, level, (int64_t)1 << level, Sc, cplx{0.0, 0.0});
-            }
-        }
-        __syncthreads();   // the next level reads its neighbours' blocks of this one (global memory, same workgroup)
-    }
-}
-
-// all levels of one system on right-hand sides held in LDS (two buffers); `lane`/`nlanes`: the threads working on this system.
-// Returns the buffer index that holds the solution.  Every thread of the workgroup must call it (barriers inside).
-template <class T>
-__device__ __forceinline__ int pcr_solve_lds(int64_t N, int nlevels, const PcrSystem<T>& S, T* b0, T* b1, int lane, int nlanes, bool active)
-{
-    for (int level = 0; level <= nlevels; level++) {
-        __syncthreads();
-        const T* in = (level & 1) ? b1 : b0;
-        T* outp = (level & 1) ? b0 : b1;
-        if (active)
-            for (int64_t kk = lane; kk < NF * N; kk += nlanes) pcr_solve_row<T>(N, kk, level, nlevels, S, in, outp);
-    }
-    __syncthreads();
-    return (nlevels + 1) & 1;
-}
-
-__device__ __forceinline__ double block_sum_512(double v, double* red)
-{
-    red[threadIdx.x] = v;
-    __syncthreads();
-    for (int s = SMALL_THREADS / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
-    return red[0];
-}
-
-// one Newton iteration after the stage evaluations F (= newton_rhs_kernel + both solves + newton_update_kernel)
-__global__ void __launch_bounds__(SMALL_THREADS) newton_small_kernel(const double* __restrict__ F, const double* __restrict__ y, const double* __restrict__ scale,
-                                                                     int64_t N, int nlevels, double M_real, cplx M_c, PcrSystem<double> Sr, PcrSystem<cplx> Sc,
-                                                                     double* __restrict__ W, double* __restrict__ Z, double* __restrict__ YS,
-                                                                     double* __restrict__ out, int32_t* __restrict__ flags)
-{
-    __shared__ double br[2 * NF * SMALL_N];
-    __shared__ cplx bc[2 * NF * SMALL_N];
-    __shared__ double red[SMALL_THREADS];
-    const int64_t n = NF * N;
-    const bool real_half = threadIdx.x < SMALL_THREADS / 2;
-    const int lane = real_half ? threadIdx.x : threadIdx.x - SMALL_THREADS / 2;
-    for (int64_t kk = lane; kk < n; kk += SMALL_THREADS / 2) {
-        const int64_t i = to_field_major(kk, N);
-        const double f0 = F[i], f1 = F[n + i], f2 = F[2 * n + i];
-        if (real_half) {
-            if (!(isfinite(f0) && isfinite(f1) && isfinite(f2))) atomicOr(flags, 1);
-            br[kk] = ((f0 * TI00 + f1 * TI01) + f2 * TI02) - M_real * W[i];
-        } else {
-            const cplx w = {W[n + i], W[2 * n + i]};
-            const cplx fc = {(f0 * TI10 + f1 * TI11) + f2 * TI12, (f0 * TI20 + f1 * TI21) + f2 * TI22};
-            bc[kk] = fc - M_c * w;
-        }
-    }
-    // both systems level by level (the two halves of the workgroup share the barriers)
-    double* xr = nullptr;
-    cplx* xc = nullptr;
-    {
-        constexpr int HALF = NF * SMALL_N;
-        for (int level = 0; level <= nlevels; level++) {
-            __syncthreads();
-            const int a = (level & 1) * HALF, b = HALF - a;
-            for (int64_t kk = lane; kk < n; kk += SMALL_THREADS / 2) {
-                if (real_half) pcr_solve_row<double>(N, kk, level, nlevels, Sr, br + a, br + b);
-                else pcr_solve_row<cplx>(N, kk, level, nlevels, Sc, bc + a, bc + b);
-            }
-        }
-        __syncthreads();
-        xr = br + ((nlevels + 1) & 1) * HALF;
-        xc = bc + ((nlevels + 1) & 1) * HALF;
-    }
-    double ss = 0;
-    for (int64_t kk = threadIdx.x; kk < n; kk += SMALL_THREADS) {
-        const int64_t i = to_field_major(kk, N);
-        const double d0 = xr[kk], d1 = xc[kk].re, d2 = xc[kk].im;
-        const double s = scale[i];
-        const double e0 = d0 / s, e1 = d1 / s, e2 = d2 / s;
-        ss += (e0 * e0 + e1 * e1) + e2 * e2;
-        const double w0 = W[i] + d0, w1 = W[n + i] + d1, w2 = W[2 * n + i] + d2;
-        W[i] = w0; W[n + i] = w1; W[2 * n + i] = w2;
-        const double z0 = (T00 * w0 + T01 * w1) + T02 * w2, z1 = (T10 * w0 + T11 * w1) + T12 * w2, z2 = (T20 * w0 + T21 * w1) + T22 * w2;
-        Z[i] = z0; Z[n + i] = z1; Z[2 * n + i] = z2;
-        const double yi = y[i];
-        YS[i] = yi + z0; YS[n + i] = yi + z1; YS[2 * n + i] = yi + z2;
-    }
-    const double tot = block_sum_512(ss, red);
-    if (threadIdx.x == 0) out[0] = tot;
-}
-
-// the error estimate (= error_rhs_kernel + the real solve + error_norm_kernel)
-__global__ void __launch_bounds__(SMALL_THREADS) error_small_kernel(const double* __restrict__ fvec, const double* __restrict__ Z, const double* __restrict__ y,
-                                                                    int64_t N, int nlevels, double E0, double E1, double E2, double h, double rtol, double atol,
-                                                                    PcrSystem<double> Sr, double* __restrict__ ynew, double* __restrict__ err,
-                                                                    double* __restrict__ yerr, double* __restrict__ out)
-{
-    __shared__ double br[2 * NF * SMALL_N];
-    __shared__ double red[SMALL_THREADS];
-    const int64_t n = NF * N;
-    for (int64_t kk = threadIdx.x; kk < n; kk += SMALL_THREADS) {
-        const int64_t i = to_field_major(kk, N);
-        const double ZE = ((Z[i] * E0 + Z[n + i] * E1) + Z[2 * n + i] * E2) / h;
-        br[kk] = fvec[i] + ZE;
-        ynew[i] = y[i] + Z[2 * n + i];
-    }
-    const int where = pcr_solve_lds<double>(N, nlevels, Sr, br, br + NF * SMALL_N, threadIdx.x, SMALL_THREADS, true);
-    const double* x = br + where * NF * SMALL_N;
-    double ss = 0;
-    for (int64_t kk = threadIdx.x; kk < n; kk += SMALL_THREADS) {
-        const int64_t i = to_field_major(kk, N);
-        const double e = x[kk];
-        const double yi = y[i], yn = yi + Z[2 * n + i];
-        const double a = fabs(yi), b = fabs(yn);
-        const double s = atol + ((a > b || a != a) ? a : b) * rtol;
-        const double q = e / s;
-        ss += q * q;
-        err[i] = e;
-        yerr[i] = yi + e;
-    }
-    const double tot = block_sum_512(ss, red);
-    if (threadIdx.x == 0) out[0] = tot;
-}
-
 // ---- element-wise pieces of solve_collocation_system (radau.py:47-130) and _step_impl (:404-537) -------------------------
 // scale = atol + |y| rtol;  Z = Z0, W = TI Z0, YS = y + Z
 __global__ void __launch_bounds__(256) newton_begin_kernel(const double* __restrict__ y, const double* __restrict__ Z0, int64_t n, double rtol, double atol,

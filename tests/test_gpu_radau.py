@@ -41,7 +41,7 @@ def _close_counts(res, nfev, njev, nlu, steps):
     return abs(res.nfev - nfev) <= 6 and abs(res.njev - njev) <= 1 and abs(res.nlu - nlu) <= 2 and abs(res.n_accepted - steps) <= 1
 
 
-@pytest.mark.parametrize("solver", [0, 1, 2])    # 0: block PCR (default; here: the fused small-grid kernels), 1: sequential block Thomas, 2: PCR, one launch per level
+@pytest.mark.parametrize("solver", [0, 1])       # 0: block parallel cyclic reduction (default), 1: sequential block Thomas
 @pytest.mark.parametrize("groups", ["scipy", None])
 @pytest.mark.parametrize("name", ["A", "matlab", "A_N64_tight"])
 def test_radau_reproduces_scipy_on_the_reference_rhs(oracle, name, groups, solver):
