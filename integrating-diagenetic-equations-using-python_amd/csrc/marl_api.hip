@@ -1289,9 +1289,9 @@ int radau_factor(marl_ctx* ctx, RadauWork& w, double mu_r, cplx mu_c)
         LAUNCH_OK(ctx);
         return 0;
     }
-    const dim3 grid((unsigned)((N + 63) / 64), 2);
+    const dim3 grid((unsigned)((N + radau::PCR_CELLS_PER_BLOCK - 1) / radau::PCR_CELLS_PER_BLOCK), 2);
     for (int level = -1; level < w.nlevels; level++) {
-        hipLaunchKernelGGL(radau::pcr_factor_kernel, grid, dim3(64), 0, ctx->stream, w.J, N, level, mu_r, mu_c, w.Sr, w.Sc);
+        hipLaunchKernelGGL(radau::pcr_factor_kernel, grid, dim3(256), 0, ctx->stream, w.J, N, level, mu_r, mu_c, w.Sr, w.Sc);
         LAUNCH_OK(ctx);
     }
     return 0;

@@ -306,76 +306,6 @@ __global__ void __launch_bounds__(64) solve_kernel(const double* __restrict__ J,
 // and the last D^-1 (one thread per cell per level; the 5 x 5 inverses by Gauss-Jordan with partial pivoting); a solve = the b
 // recurrences (one thread per unknown per level).  One launch per level: a grid-wide dependency sits between levels.
 // Accuracy against dense LU on this model's matrices (h = 1e-6 ... 0.1, condition up to 1e20): <= 6e-10 relative.
-template <class T>
-__device__ __forceinline__ void zero25(T (&m)[25], T like)
-{
-#pragma unroll
-    for (int e = 0; e < 25; e++) m[e] = lift(0.0, like);
-}
-
-// C += sign * A * X, X streamed from memory row by row (5 live values instead of 25)
-template <class T>
-__device__ __forceinline__ void mul_acc(const T (&A)[25], const T* __restrict__ X, T (&C)[25], double sign)
-{
-#pragma unroll
-    for (int k = 0; k < NF; k++) {
-        T x[NF];
-#pragma unroll
-        for (int c = 0; c < NF; c++) x[c] = sign * X[k * NF + c];
-#pragma unroll
-        for (int r = 0; r < NF; r++)
-#pragma unroll
-            for (int c = 0; c < NF; c++) C[r * NF + c] = C[r * NF + c] + A[r * NF + k] * x[c];
-    }
-}
-
-// inv = D^-1 by Gauss-Jordan with partial pivoting (D is destroyed)
-template <class T>
-__device__ __forceinline__ void gj_inverse(T (&D)[25], T (&inv)[25])
-{
-    const T like = D[0];
-#pragma unroll
-    for (int r = 0; r < NF; r++)
-#pragma unroll
-        for (int c = 0; c < NF; c++) inv[r * NF + c] = lift(r == c ? 1.0 : 0.0, like);
-#pragma unroll
-    for (int k = 0; k < NF; k++) {
-        int p = k;
-        double best = abs1(D[k * NF + k]);
-#pragma unroll
-        for (int r = k + 1; r < NF; r++) {
-            const double a = abs1(D[r * NF + k]);
-            if (a > best) { best = a; p = r; }
-        }
-#pragma unroll
-        for (int r = k + 1; r < NF; r++) {
-            const bool sw = (p == r);
-#pragma unroll
-            for (int c = 0; c < NF; c++) {
-                T t = D[k * NF + c];
-                D[k * NF + c] = sw ? D[r * NF + c] : t;
-                D[r * NF + c] = sw ? t : D[r * NF + c];
-                t = inv[k * NF + c];
-                inv[k * NF + c] = sw ? inv[r * NF + c] : t;
-                inv[r * NF + c] = sw ? t : inv[r * NF + c];
-            }
-        }
-        const T pv = recip(D[k * NF + k]);
-#pragma unroll
-        for (int c = 0; c < NF; c++) { D[k * NF + c] = D[k * NF + c] * pv; inv[k * NF + c] = inv[k * NF + c] * pv; }
-#pragma unroll
-        for (int r = 0; r < NF; r++) {
-            if (r == k) continue;
-            const T m = D[r * NF + k];
-#pragma unroll
-            for (int c = 0; c < NF; c++) {
-                D[r * NF + c] = D[r * NF + c] - m * D[k * NF + c];
-                inv[r * NF + c] = inv[r * NF + c] - m * inv[k * NF + c];
-            }
-        }
-    }
-}
-
 // storage of one system: blocks are 25 T per cell
 template <class T>
 struct PcrSystem {
@@ -384,82 +314,130 @@ struct PcrSystem {
     T* b[2];                                 // ping-pong right-hand sides, cell-major
 };
 
-template <class T>
-__device__ void pcr_init_cell(const double* __restrict__ J, int64_t N, int64_t i, T mu, const PcrSystem<T>& S)
-{
-    T D[25], inv[25];
-    const double* Jd = J + (i * 3 + 1) * 25;
-#pragma unroll
-    for (int e = 0; e < 25; e++) {
-        T a = lift(-Jd[e], mu);
-        if (e % 6 == 0) a = a + mu;
-        D[e] = a;
-        S.D[0][i * 25 + e] = a;
-        S.L[0][i * 25 + e] = lift(i > 0 ? -J[(i * 3 + 0) * 25 + e] : 0.0, mu);
-        S.U[0][i * 25 + e] = lift(i < N - 1 ? -J[(i * 3 + 2) * 25 + e] : 0.0, mu);
-    }
-    gj_inverse(D, inv);
-#pragma unroll
-    for (int e = 0; e < 25; e++) S.Dinv[0][i * 25 + e] = inv[e];
-}
+// Factorisation with ONE LANE PER BLOCK ELEMENT: a cell's 5 x 5 blocks are spread over 25 lanes of a 32-lane group (8 cells per
+// 256-thread workgroup); block products and the Gauss-Jordan inverse read their operands' rows / columns from a small LDS stage.
+// (The first version gave a whole cell to one lane - ~250 live complex values, 1.7 KB of scratch, 73 us per level at N = 200, 73 % of
+// the GPU time of a run; this one issues ~150 instructions per lane and level.)
+constexpr int PCR_CELLS_PER_BLOCK = 8;
 
 template <class T>
-__device__ void pcr_level_cell(int64_t N, int64_t i, int level, int64_t s, const PcrSystem<T>& S, T like)
+struct PcrStage {   // per cell group, in LDS
+    T A[25], B[25], C[25];
+};
+
+// this lane's element (r, c) of  A * B
+template <class T>
+__device__ __forceinline__ T mm_elem(const T* A, const T* B, int r, int c)
 {
+    T acc = A[r * NF] * B[c];
+#pragma unroll
+    for (int k = 1; k < NF; k++) acc = acc + A[r * NF + k] * B[k * NF + c];
+    return acc;
+}
+
+// Gauss-Jordan inverse with partial pivoting; d = this lane's element of D (destroyed), returns its element of D^-1.
+// All 256 threads call it (barriers inside); lanes with e >= 25 idle.
+template <class T>
+__device__ __forceinline__ T gj_inverse_elem(T d, int e, int r, int c, bool act, PcrStage<T>& st)
+{
+    T v = lift(r == c ? 1.0 : 0.0, d);
+#pragma unroll
+    for (int k = 0; k < NF; k++) {
+        __syncthreads();
+        if (act) { st.A[e] = d; st.B[e] = v; }
+        __syncthreads();
+        if (act) {
+            int p = k;
+            double best = abs1(st.A[k * NF + k]);
+#pragma unroll
+            for (int rr = k + 1; rr < NF; rr++) {
+                const double a = (rr > k) ? abs1(st.A[rr * NF + k]) : -1.0;
+                if (a > best) { best = a; p = rr; }
+            }
+            // rows k and p swapped: this lane's row index in the unswapped matrix
+            const int src = (r == k) ? p : ((r == p) ? k : r);
+            const T dk = st.A[p * NF + c], vk = st.B[p * NF + c];          // (swapped) pivot row, this column
+            const T pv = recip(st.A[p * NF + k]);                          // 1 / pivot
+            const T dk_s = dk * pv, vk_s = vk * pv;                        // scaled pivot row
+            if (r == k) { d = dk_s; v = vk_s; }
+            else {
+                const T m = st.A[src * NF + k];                            // this row's entry in the pivot column
+                d = st.A[src * NF + c] - m * dk_s;
+                v = st.B[src * NF + c] - m * vk_s;
+            }
+        }
+    }
+    return v;
+}
+
+// level < 0: blocks of level 0 from J and their inverses; else one PCR level (stride s = 2^level)
+template <class T>
+__device__ void pcr_factor_group(const double* __restrict__ J, int64_t N, int level, T mu, const PcrSystem<T>& S, PcrStage<T>& st)
+{
+    const int g = threadIdx.x >> 5, e = threadIdx.x & 31;
+    const int64_t i = (int64_t)blockIdx.x * PCR_CELLS_PER_BLOCK + g;
+    const bool act = e < 25 && i < N;
+    const int r = act ? e / NF : 0, c = act ? e % NF : 0;
+    const int64_t ic = (i < N) ? i : N - 1;   // idle groups shadow the last cell (uniform barriers, no stores)
+    T d;
+    if (level < 0) {
+        d = lift(-J[(ic * 3 + 1) * 25 + (act ? e : 0)], mu);
+        if (r == c) d = d + mu;
+        if (act) {
+            S.D[0][i * 25 + e] = d;
+            S.L[0][i * 25 + e] = lift(i > 0 ? -J[(i * 3 + 0) * 25 + e] : 0.0, mu);
+            S.U[0][i * 25 + e] = lift(i < N - 1 ? -J[(i * 3 + 2) * 25 + e] : 0.0, mu);
+        }
+        const T inv = gj_inverse_elem<T>(d, e, r, c, act, st);
+        if (act) S.Dinv[0][i * 25 + e] = inv;
+        return;
+    }
     const int cur = level & 1, nxt = cur ^ 1;
-    T A[25], Dn[25], R[25];
-#pragma unroll
-    for (int e = 0; e < 25; e++) Dn[e] = S.D[cur][i * 25 + e];
-    T* al = S.alpha + ((int64_t)level * N + i) * 25;
-    T* ga = S.gamma + ((int64_t)level * N + i) * 25;
-    // lower side
-    zero25(R, like);
-    if (i - s >= 0) {
-        T Li[25];
-#pragma unroll
-        for (int e = 0; e < 25; e++) Li[e] = S.L[cur][i * 25 + e];
-        zero25(A, like);
-        mul_acc(Li, S.Dinv[cur] + (i - s) * 25, A, -1.0);     // alpha = -L D_{i-s}^-1
-        mul_acc(A, S.U[cur] + (i - s) * 25, Dn, 1.0);
-        mul_acc(A, S.L[cur] + (i - s) * 25, R, 1.0);
-    } else {
-        zero25(A, like);
+    const int64_t s = (int64_t)1 << level;
+    const int ee = act ? e : 0;
+    d = S.D[cur][ic * 25 + ee];
+    const T zero = lift(0.0, mu);
+    // lower side: alpha = -L D_{i-s}^-1;  D += alpha U_{i-s};  L' = alpha L_{i-s}
+    const bool lo = ic - s >= 0;
+    T al = zero, ln = zero;
+    __syncthreads();
+    if (act && lo) { st.A[e] = S.L[cur][i * 25 + e]; st.B[e] = S.Dinv[cur][(i - s) * 25 + e]; }
+    __syncthreads();
+    if (act && lo) al = lift(-1.0, mu) * mm_elem<T>(st.A, st.B, r, c);
+    __syncthreads();
+    if (act && lo) { st.A[e] = al; st.B[e] = S.U[cur][(i - s) * 25 + e]; st.C[e] = S.L[cur][(i - s) * 25 + e]; }
+    __syncthreads();
+    if (act && lo) { d = d + mm_elem<T>(st.A, st.B, r, c); ln = mm_elem<T>(st.A, st.C, r, c); }
+    // upper side: gamma = -U D_{i+s}^-1;  D += gamma L_{i+s};  U' = gamma U_{i+s}
+    const bool hi = ic + s < N;
+    T ga = zero, un = zero;
+    __syncthreads();
+    if (act && hi) { st.A[e] = S.U[cur][i * 25 + e]; st.B[e] = S.Dinv[cur][(i + s) * 25 + e]; }
+    __syncthreads();
+    if (act && hi) ga = lift(-1.0, mu) * mm_elem<T>(st.A, st.B, r, c);
+    __syncthreads();
+    if (act && hi) { st.A[e] = ga; st.B[e] = S.L[cur][(i + s) * 25 + e]; st.C[e] = S.U[cur][(i + s) * 25 + e]; }
+    __syncthreads();
+    if (act && hi) { d = d + mm_elem<T>(st.A, st.B, r, c); un = mm_elem<T>(st.A, st.C, r, c); }
+    if (act) {
+        S.alpha[((int64_t)level * N + i) * 25 + e] = al;
+        S.gamma[((int64_t)level * N + i) * 25 + e] = ga;
+        S.L[nxt][i * 25 + e] = ln;
+        S.U[nxt][i * 25 + e] = un;
+        S.D[nxt][i * 25 + e] = d;
     }
-#pragma unroll
-    for (int e = 0; e < 25; e++) { al[e] = A[e]; S.L[nxt][i * 25 + e] = R[e]; }
-    // upper side
-    zero25(R, like);
-    if (i + s < N) {
-        T Ui[25];
-#pragma unroll
-        for (int e = 0; e < 25; e++) Ui[e] = S.U[cur][i * 25 + e];
-        zero25(A, like);
-        mul_acc(Ui, S.Dinv[cur] + (i + s) * 25, A, -1.0);     // gamma = -U D_{i+s}^-1
-        mul_acc(A, S.L[cur] + (i + s) * 25, Dn, 1.0);
-        mul_acc(A, S.U[cur] + (i + s) * 25, R, 1.0);
-    } else {
-        zero25(A, like);
-    }
-#pragma unroll
-    for (int e = 0; e < 25; e++) { ga[e] = A[e]; S.U[nxt][i * 25 + e] = R[e]; S.D[nxt][i * 25 + e] = Dn[e]; }
-    gj_inverse(Dn, R);
-#pragma unroll
-    for (int e = 0; e < 25; e++) S.Dinv[nxt][i * 25 + e] = R[e];
+    const T inv = gj_inverse_elem<T>(d, e, r, c, act, st);
+    if (act) S.Dinv[nxt][i * 25 + e] = inv;
 }
 
 // blockIdx.y: 0 real system, 1 complex system.  level < 0: initialise from J.
-__global__ void __launch_bounds__(64) pcr_factor_kernel(const double* __restrict__ J, int64_t N, int level, double mu_r, cplx mu_c, PcrSystem<double> Sr,
-                                                        PcrSystem<cplx> Sc)
+__global__ void __launch_bounds__(256) pcr_factor_kernel(const double* __restrict__ J, int64_t N, int level, double mu_r, cplx mu_c, PcrSystem<double> Sr,
+                                                         PcrSystem<cplx> Sc)
 {
-    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (i >= N) return;
-    if (blockIdx.y == 0) {
-        if (level < 0) pcr_init_cell<double>(J, N, i, mu_r, Sr);
-        else pcr_level_cell<double>(N, i, level, (int64_t)1 << level, Sr, 0.0);
-    } else {
-        if (level < 0) pcr_init_cell<cplx>(J, N, i, mu_c, Sc);
-        else pcr_level_cell<cplx>(N, i, level, (int64_t)1 << level, Sc, cplx{0.0, 0.0});
-    }
+    __shared__ PcrStage<cplx> stage[PCR_CELLS_PER_BLOCK];   // (the real system uses the same bytes)
+    const int g = threadIdx.x >> 5;
+    if (blockIdx.y == 0) pcr_factor_group<double>(J, N, level, mu_r, Sr, *reinterpret_cast<PcrStage<double>*>(&stage[g]));
+    else pcr_factor_group<cplx>(J, N, level, mu_c, Sc, stage[g]);
 }
 
 template <class T>
