@@ -84,7 +84,8 @@ def test_radau_high_porosity_case(oracle):
     for mine, ref in ((res.nfev, g["nfev"]), (res.njev, g["njev"]), (res.nlu, g["nlu"]), (res.n_accepted, len(g["step_times"]) - 1)):
         assert abs(mine - int(ref)) <= 0.05 * int(ref), (mine, int(ref))
     assert np.max(np.abs(res.y_final - g["y_final"])) <= 1e-4
-    assert res.t_events[4].size == 2 and np.allclose(res.t_events[4], g["t_events"][:2], atol=1e-4)   # porosity crosses one twice
+    # porosity crosses one twice: the first crossing lies before the trajectories part, the second long after
+    assert res.t_events[4].size == 2 and abs(res.t_events[4][0] - g["t_events"][0]) <= 1e-6 and abs(res.t_events[4][1] - g["t_events"][1]) <= 1e-3
     gold = np.load(f"{GOLDEN}/ref_final_high_porosity_0.8.npy")
     np.testing.assert_allclose(res.y_final.reshape(5, 200), gold, rtol=0.1, atol=0.01)
     eq.close()
