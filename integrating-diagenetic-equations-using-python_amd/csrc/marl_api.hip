@@ -1205,11 +1205,13 @@ int marl_slab_run(marl_ctx* ctx, marl_stats* stats)
 namespace {
 using radau::cplx;
 
+constexpr int kRadauPartials = 256;   // workgroups of the norm + update kernels on large grids
+
 struct RadauWork {
     double *y, *f, *fnew, *ynew, *err, *yerr, *yold, *scale, *tmp;
     double *Z, *W, *F, *Z0, *Q, *YS;
     double *fac, *h, *yscale, *maxdiff, *scl, *hnew, *Jraw, *YP, *FN;
-    double *J, *Dinv_r, *Up_r, *rhs_r, *out;
+    double *J, *Dinv_r, *Up_r, *rhs_r, *out, *partial;
     cplx *Dinv_c, *Up_c, *rhs_c;
     int32_t *small, *groups, *flags;
     int ng = 0;
@@ -1244,7 +1246,7 @@ int radau_alloc(marl_ctx* ctx, RadauWork& w, const int32_t* groups_host)
     int nlev = 0;
     while (((int64_t)1 << nlev) < N) nlev++;
     const size_t pcr_real = (size_t)N * 25 * (8 + 2 * (size_t)nlev) + 2 * (size_t)n;   // L, D, U, Dinv ping-pong; alpha, gamma per level; b ping-pong
-    const size_t doubles = (size_t)n * (9 + 6 * 3 + 6 + 15 + 2 * (size_t)ng + 15 + 10 + 20 + 1 + 2) + 64 + (size_t)n + 3 * pcr_real;
+    const size_t doubles = (size_t)n * (9 + 6 * 3 + 6 + 15 + 2 * (size_t)ng + 15 + 10 + 20 + 1 + 2) + 64 + kRadauPartials + (size_t)n + 3 * pcr_real;
     if (ctx->rd_cap < doubles) {
         if (ctx->rd_arena) HIP_OK(ctx, hipFree(ctx->rd_arena));
         ctx->rd_arena = nullptr; ctx->rd_cap = 0;
@@ -1260,7 +1262,7 @@ int radau_alloc(marl_ctx* ctx, RadauWork& w, const int32_t* groups_host)
     w.YP = take((size_t)ng * n); w.FN = take((size_t)ng * n);
     w.J = take(15 * n); w.Dinv_r = take(5 * n); w.Up_r = take(5 * n);
     w.Dinv_c = (cplx*)take(10 * n); w.Up_c = (cplx*)take(10 * n);
-    w.rhs_r = take(n); w.rhs_c = (cplx*)take(2 * n); w.out = take(8);
+    w.rhs_r = take(n); w.rhs_c = (cplx*)take(2 * n); w.out = take(8); w.partial = take(kRadauPartials);
     w.small = (int32_t*)take((n + 1) / 2 + 1); w.groups = (int32_t*)take((n + 1) / 2 + 1); w.flags = (int32_t*)take(2);
     w.ng = ng;
     w.nlevels = nlev;
@@ -1279,6 +1281,8 @@ int radau_alloc(marl_ctx* ctx, RadauWork& w, const int32_t* groups_host)
 }
 
 inline unsigned blocks256(int64_t n) { return (unsigned)((n + 255) / 256); }
+// workgroups of the norm kernels: one up to 8192 unknowns, then one per 4096, at most kRadauPartials
+inline int radau_norm_blocks(int64_t n) { return n <= 8192 ? 1 : (int)std::min<int64_t>(256, (n + 4095) / 4096); }
 
 // factorise  mu_r I - J  and  mu_c I - J  (block PCR: 1 + ceil(log2 N) launches; or sequential block Thomas: 1 launch)
 int radau_factor(marl_ctx* ctx, RadauWork& w, double mu_r, cplx mu_c)
@@ -1340,6 +1344,21 @@ int radau_num_jac(marl_ctx* ctx, RadauWork& w, const double* y, const double* f0
     hipLaunchKernelGGL(radau::fd_finish_kernel, dim3(blocks256(n)), dim3(256), 0, ctx->stream, f0, w.FN, w.groups, N, w.fac, w.h, w.maxdiff, w.scl, w.small,
                        w.hnew, w.Jraw, w.J);
     LAUNCH_OK(ctx);
+    return 0;
+}
+
+// err = the solved right-hand side; sum (err / scale)^2 -> w.out[0]
+int radau_error_norm(marl_ctx* ctx, RadauWork& w, double rtol, double atol)
+{
+    const int64_t N = ctx->N;
+    const int nbk = radau_norm_blocks(NF * N);
+    hipLaunchKernelGGL(radau::error_norm_kernel, dim3(nbk), dim3(1024), 0, ctx->stream, w.rhs_r, w.y, w.ynew, N, rtol, atol, w.err, w.yerr,
+                       nbk > 1 ? w.partial : w.out);
+    LAUNCH_OK(ctx);
+    if (nbk > 1) {
+        hipLaunchKernelGGL(radau::sum_partials_kernel, dim3(1), dim3(1), 0, ctx->stream, w.partial, nbk, w.out);
+        LAUNCH_OK(ctx);
+    }
     return 0;
 }
 
@@ -1508,8 +1527,16 @@ int radau_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_st
                     hipLaunchKernelGGL(radau::newton_rhs_kernel, gn, b256, 0, ctx->stream, w.F, w.W, N, M_real, M_c, w.rhs_r, w.rhs_c, w.flags);
                     LAUNCH_OK(ctx);
                     if (int rc = radau_solve(ctx, w, true)) return rc;
-                    hipLaunchKernelGGL(radau::newton_update_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.y, w.rhs_r, w.rhs_c, w.scale, N, w.W, w.Z, w.YS, w.out);
-                    LAUNCH_OK(ctx);
+                    {
+                        const int nbk = radau_norm_blocks(n);
+                        hipLaunchKernelGGL(radau::newton_update_kernel, dim3(nbk), dim3(1024), 0, ctx->stream, w.y, w.rhs_r, w.rhs_c, w.scale, N, w.W, w.Z, w.YS,
+                                           nbk > 1 ? w.partial : w.out);
+                        LAUNCH_OK(ctx);
+                        if (nbk > 1) {
+                            hipLaunchKernelGGL(radau::sum_partials_kernel, dim3(1), dim3(1), 0, ctx->stream, w.partial, nbk, w.out);
+                            LAUNCH_OK(ctx);
+                        }
+                    }
                     double ss;
                     int nonfinite;
                     if (int rc = radau_read(ctx, w, &ss, &nonfinite)) return rc;
@@ -1540,8 +1567,7 @@ int radau_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_st
             hipLaunchKernelGGL(radau::error_rhs_kernel, gn, b256, 0, ctx->stream, w.f, w.Z, w.y, N, E3[0], E3[1], E3[2], h, w.rhs_r, w.ynew);
             LAUNCH_OK(ctx);
             if (int rc = radau_solve(ctx, w, false)) return rc;
-            hipLaunchKernelGGL(radau::error_norm_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.rhs_r, w.y, w.ynew, N, rtol, atol, w.err, w.yerr, w.out);
-            LAUNCH_OK(ctx);
+            if (int rc = radau_error_norm(ctx, w, rtol, atol)) return rc;
             double ss;
             if (int rc = radau_read(ctx, w, &ss, nullptr)) return rc;
             error_norm = std::sqrt(ss) / std::sqrt((double)n);
@@ -1552,8 +1578,7 @@ int radau_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_st
                 hipLaunchKernelGGL(radau::error_rhs_kernel, gn, b256, 0, ctx->stream, w.tmp, w.Z, w.y, N, E3[0], E3[1], E3[2], h, w.rhs_r, w.ynew);
                 LAUNCH_OK(ctx);
                 if (int rc = radau_solve(ctx, w, false)) return rc;
-                hipLaunchKernelGGL(radau::error_norm_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.rhs_r, w.y, w.ynew, N, rtol, atol, w.err, w.yerr, w.out);
-                LAUNCH_OK(ctx);
+                if (int rc = radau_error_norm(ctx, w, rtol, atol)) return rc;
                 if (int rc = radau_read(ctx, w, &ss, nullptr)) return rc;
                 error_norm = std::sqrt(ss) / std::sqrt((double)n);
             }

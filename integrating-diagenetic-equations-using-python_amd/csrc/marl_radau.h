@@ -512,8 +512,9 @@ __global__ void __launch_bounds__(256) newton_rhs_kernel(const double* __restric
     rhs_c[kk] = fc - M_c * w;
 }
 
-// one workgroup: out[0] = sum (dW / scale)^2 over the 3n entries; then W += dW, Z = T W, YS = y + Z (kept only if the host
-// goes on: a `break` of the Newton loop discards W and Z anyway, radau.py:112-119)
+// out[blockIdx.x] = this workgroup's share of  sum (dW / scale)^2  over the 3n entries (one workgroup: the sum itself; more:
+// sum_partials_kernel adds them in index order); then W += dW, Z = T W, YS = y + Z (kept only if the host goes on: a `break` of
+// the Newton loop discards W and Z anyway, radau.py:112-119)
 __global__ void __launch_bounds__(1024) newton_update_kernel(const double* __restrict__ y, const double* __restrict__ rhs_r, const cplx* __restrict__ rhs_c,
                                                              const double* __restrict__ scale, int64_t N, double* __restrict__ W, double* __restrict__ Z,
                                                              double* __restrict__ YS, double* __restrict__ out)
@@ -521,7 +522,7 @@ __global__ void __launch_bounds__(1024) newton_update_kernel(const double* __res
     __shared__ double red[1024];
     const int64_t n = NF * N;
     double ss = 0;
-    for (int64_t kk = threadIdx.x; kk < n; kk += 1024) {
+    for (int64_t kk = (int64_t)blockIdx.x * 1024 + threadIdx.x; kk < n; kk += (int64_t)gridDim.x * 1024) {
         const int64_t i = to_field_major(kk, N);
         const double d0 = rhs_r[kk], d1 = rhs_c[kk].re, d2 = rhs_c[kk].im;
         const double s = scale[i];
@@ -540,7 +541,15 @@ __global__ void __launch_bounds__(1024) newton_update_kernel(const double* __res
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = red[0];
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
+// out[0] = partial[0] + partial[1] + ... (index order: reproducible)
+__global__ void sum_partials_kernel(const double* __restrict__ partial, int n, double* __restrict__ out)
+{
+    double s = 0;
+    for (int i = 0; i < n; i++) s += partial[i];
+    out[0] = s;
 }
 
 // right-hand side of the error estimate: fvec + Z^T E / h  (radau.py:468-470, :476), cell-major; also y_new = y + Z[2]
@@ -556,7 +565,7 @@ __global__ void __launch_bounds__(256) error_rhs_kernel(const double* __restrict
     ynew[i] = y[i] + Z[2 * n + i];
 }
 
-// one workgroup: err (field-major) = solution; scale = atol + max(|y|, |y_new|) rtol; out[0] = sum (err / scale)^2; yerr = y + err
+// err (field-major) = solution; scale = atol + max(|y|, |y_new|) rtol; out[blockIdx.x] = partial sum (err / scale)^2; yerr = y + err
 __global__ void __launch_bounds__(1024) error_norm_kernel(const double* __restrict__ rhs_r, const double* __restrict__ y, const double* __restrict__ ynew,
                                                           int64_t N, double rtol, double atol, double* __restrict__ err, double* __restrict__ yerr,
                                                           double* __restrict__ out)
@@ -564,7 +573,7 @@ __global__ void __launch_bounds__(1024) error_norm_kernel(const double* __restri
     __shared__ double red[1024];
     const int64_t n = NF * N;
     double ss = 0;
-    for (int64_t kk = threadIdx.x; kk < n; kk += 1024) {
+    for (int64_t kk = (int64_t)blockIdx.x * 1024 + threadIdx.x; kk < n; kk += (int64_t)gridDim.x * 1024) {
         const int64_t i = to_field_major(kk, N);
         const double e = rhs_r[kk];
         const double a = fabs(y[i]), b = fabs(ynew[i]);
@@ -580,7 +589,7 @@ __global__ void __launch_bounds__(1024) error_norm_kernel(const double* __restri
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = red[0];
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
 }
 
 // dense output coefficients Q = Z^T P (radau.py:539-541), stored [i][3]
