@@ -452,10 +452,34 @@ def main():
             extra["BASELINE_configs4_dd_rk45"] = {"value": float(1 << 22) * 500 / w, "unit": "grid-point-steps/s (attempted steps)",
                                                   "n_ranks": world, "N": 1 << 22, "attempts": 500, "scaling": "strong",
                                                   "parallelism": "1-D domain decomposition; one all-gather (halo strips + record) per attempt", **info}
+        def x_radau():
+            # the reference's DEFAULT solver (implicit Radau) through marl_integrate_radau: time to solution of
+            # Scenario A to T* = 13 190 yr (rtol = atol = 1e-3), every rank its own copy; the CPU oracle beside it on rank 0
+            res = {}
+            for Nr in (200, 4000, 64000):
+                pr = base | {"Phi0": 0.6, "PhiIni": 0.5, "PhiNR": 0.6, "N": Nr}
+                y0 = np.concatenate([np.full(Nr, pr[k]) for k in ("CAIni", "CCIni", "cCaIni", "cCO3Ini", "PhiIni")])
+                eq = LMAHeureuxPorosityDiff.from_scenario(pr, device=local_rank)
+                eq.use_stream(stream.cuda_stream)
+                eq.integrate_radau(y0, (0.0, 1e-4), 1e-6, 1e-3, 1e-3, events=False)     # allocations, module load
+                t0 = time.perf_counter()
+                r = eq.integrate_radau(y0, (0.0, 1.0), 1e-6, 1e-3, 1e-3)
+                e = {"seconds": time.perf_counter() - t0, "status": r.status, "steps": r.n_accepted, "nfev": r.nfev, "njev": r.njev, "nlu": r.nlu}
+                eq.close()
+                if rank == 0 and Nr <= 4000 and not args.no_cpu_baseline:
+                    from oracle import oracle as orc
+                    t0 = time.perf_counter()
+                    _, st, *_ = orc.radau(orc.params_from_dict(pr), Nr, y0, 0.0, 1.0, 1e-6, 1e-3, 1e-3)
+                    e["cpu_oracle_seconds_1_core"] = time.perf_counter() - t0
+                    e["cpu_oracle_nfev_njev_nlu"] = [int(st.nfev), int(st.njev), int(st.nlu)]
+                res[f"N{Nr}"] = e
+            extra["implicit_radau_scenarioA_to_Tstar"] = res
+
         guarded("BASELINE_configs1_rk4_N65536", x_n65536)
         guarded("rk4_N1048576_no_reuse", x_no_reuse)
         guarded("BASELINE_configs2_3_sweep_rk45", x_sweep)
         guarded("BASELINE_configs4_dd_rk45", x_dd)
+        guarded("implicit_radau_scenarioA_to_Tstar", x_radau)
         dog.cancel()
     emit()
     if use_dist:
