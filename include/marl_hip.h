@@ -122,6 +122,15 @@ int marl_integrate_radau(marl_ctx* ctx, double* y, double t0, double t1, double 
                          const int32_t* groups, const double* t_eval, int64_t n_eval, double* y_eval, double* t_events,
                          int64_t max_events, int64_t max_attempts, marl_stats* stats);
 
+/* A SWEEP of Radau integrations (the reference integrates one scenario per process with this solver; its tests loop over
+ * scenarios: tests/Regression_test/test_regression.py:44,74,115-116): every instance of the context with its own parameters, step-size
+ * history and Newton convergence, advanced together - each instance's step logic runs as a state machine on the device, every
+ * launch works on all instances that currently need that kind of work (csrc/marl_radau_batch.h).  y_dev: [n_instances][5N] FIELD-MAJOR
+ * device states, advanced in place; stats: host array of n_instances entries (nfev / njev / nlu / status / t as scipy counts them;
+ * monitor sign changes are counted in n_events, root times are not located in a sweep).  N <= 1638.  Synchronises. */
+int marl_sweep_radau_dev(marl_ctx* ctx, double* y_dev, double t0, double t1, double first_step, double rtol, double atol,
+                         const int32_t* groups, int64_t max_attempts, marl_stats* stats);
+
 /* ---- 1-D domain decomposition of ONE large grid (BASELINE config 5; the reference never decomposes the depth
  * axis).  One process per GPU holds a slab [g_begin, g_end) of the N_global cells in a slab context; the host
  * layer moves halo strips between neighbours and the per-rank reduction records to everybody (RCCL

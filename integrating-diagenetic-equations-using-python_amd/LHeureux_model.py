@@ -344,6 +344,17 @@ class LMAHeureuxPorosityDiff:
         self._check(rc, "marl_integrate_rk45_dev")
         return RK45Result(stats)
 
+    def sweep_radau_device(self, y_dev_ptr, t_span, first_step, rtol, atol, max_attempts=0, groups=None):
+        """Every instance of the model integrated with the reference's default solver (scipy Radau semantics), all instances
+        advanced together on the device (marl_sweep_radau_dev); device states [instances][5N] in place.  Returns one
+        :class:`RK45Result` per instance (statistics; event sign changes are counted, not located)."""
+        grp = None if groups is None else np.ascontiguousarray(groups, dtype=np.int32)
+        stats = (MarlStats * self.n_instances)()
+        rc = self._lib.marl_sweep_radau_dev(self._ctx, C.c_void_p(y_dev_ptr), float(t_span[0]), float(t_span[1]), float(first_step), float(rtol),
+                                            float(atol), _as_ptr(grp) if grp is not None else None, int(max_attempts), stats)
+        self._check(rc, "marl_sweep_radau_dev")
+        return [RK45Result(s) for s in stats]
+
     def sweep_rk45_device(self, y_dev_ptr, t_span, first_step, rtol, atol, max_attempts=0):
         stats = (MarlStats * self.n_instances)()
         rc = self._lib.marl_sweep_rk45_dev(self._ctx, C.c_void_p(y_dev_ptr), float(t_span[0]), float(t_span[1]),

@@ -15,6 +15,7 @@
 #include "../../include/marl_hip.h"
 #include "marl_kernels.h"
 #include "marl_radau.h"
+#include "marl_radau_batch.h"
 
 using namespace marl;
 
@@ -1223,7 +1224,8 @@ struct RadauWork {
     bool pcr = true;
 };
 
-int radau_alloc(marl_ctx* ctx, RadauWork& w, const int32_t* groups_host)
+// `instances` > 1: one arena per instance, all with the layout of instance 0 (`w`), `*zstride` bytes apart
+int radau_alloc(marl_ctx* ctx, RadauWork& w, const int32_t* groups_host, int64_t instances = 1, int64_t* zstride = nullptr)
 {
     const int64_t N = ctx->N, n = NF * N;
     std::vector<int32_t> g(n);
@@ -1247,11 +1249,13 @@ int radau_alloc(marl_ctx* ctx, RadauWork& w, const int32_t* groups_host)
     while (((int64_t)1 << nlev) < N) nlev++;
     const size_t pcr_real = (size_t)N * 25 * (8 + 2 * (size_t)nlev) + 2 * (size_t)n;   // L, D, U, Dinv ping-pong; alpha, gamma per level; b ping-pong
     const size_t doubles = (size_t)n * (9 + 6 * 3 + 6 + 15 + 2 * (size_t)ng + 15 + 10 + 20 + 1 + 2) + 64 + kRadauPartials + (size_t)n + 3 * pcr_real;
-    if (ctx->rd_cap < doubles) {
+    const size_t per = (doubles + 1) & ~(size_t)1;   // 16-byte multiples: complex members stay aligned in every instance
+    if (zstride) *zstride = (int64_t)(per * sizeof(double));
+    if (ctx->rd_cap < per * (size_t)instances) {
         if (ctx->rd_arena) HIP_OK(ctx, hipFree(ctx->rd_arena));
         ctx->rd_arena = nullptr; ctx->rd_cap = 0;
-        HIP_OK(ctx, hipMalloc((void**)&ctx->rd_arena, doubles * sizeof(double)));
-        ctx->rd_cap = doubles;
+        HIP_OK(ctx, hipMalloc((void**)&ctx->rd_arena, per * (size_t)instances * sizeof(double)));
+        ctx->rd_cap = per * (size_t)instances;
     }
     if (!ctx->rd_host) HIP_OK(ctx, hipHostMalloc((void**)&ctx->rd_host, 16 * sizeof(double), hipHostMallocDefault));
     double* p = ctx->rd_arena;
@@ -1274,9 +1278,10 @@ int radau_alloc(marl_ctx* ctx, RadauWork& w, const int32_t* groups_host)
     }
     w.Sr.alpha = take((size_t)nlev * 25 * N); w.Sr.gamma = take((size_t)nlev * 25 * N);
     w.Sc.alpha = (cplx*)take((size_t)nlev * 50 * N); w.Sc.gamma = (cplx*)take((size_t)nlev * 50 * N);
-    HIP_OK(ctx, hipMemcpyAsync(w.groups, g.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    if (instances > 1) HIP_OK(ctx, hipMemsetAsync(ctx->rd_arena, 0, per * (size_t)instances * sizeof(double), ctx->stream));
+    else HIP_OK(ctx, hipMemsetAsync(w.J, 0, sizeof(double) * 15 * n, ctx->stream));
+    HIP_OK(ctx, hipMemcpyAsync(w.groups, g.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));   // (one copy serves every instance)
     HIP_OK(ctx, hipStreamSynchronize(ctx->stream));   // g dies with this frame
-    HIP_OK(ctx, hipMemsetAsync(w.J, 0, sizeof(double) * 15 * n, ctx->stream));
     return 0;
 }
 
@@ -1672,6 +1677,167 @@ extern "C" int marl_integrate_radau(marl_ctx* ctx, double* y, double t0, double 
     HIP_OK(ctx, hipMemcpyAsync(y, w.y, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
+}
+
+// ---- a sweep of Radau instances (marl_radau_batch.h) -------------------------------------------------------------------------
+extern "C" int marl_sweep_radau_dev(marl_ctx* ctx, double* y_dev, double t0, double t1, double first_step, double rtol, double atol,
+                                    const int32_t* groups, int64_t max_attempts, marl_stats* stats)
+{
+    if (!ctx || !y_dev || !stats) return ctx ? fail(ctx, -1, "marl_sweep_radau_dev: invalid argument") : -1;
+    if (ctx->halo > 0) return fail(ctx, -1, "marl_sweep_radau_dev: whole-grid context required");
+    if (!(first_step > 0) || !(t1 >= t0)) return fail(ctx, -1, "radau: need first_step > 0 and t1 >= t0 (forward integration)");
+    if (t1 > t0 && first_step > t1 - t0) return fail(ctx, -1, "radau: `first_step` exceeds bounds");
+    if (!(rtol > 0) || !(atol >= 0)) return fail(ctx, -1, "radau: tolerances must be positive");
+    if (ctx->batch > 65535) return fail(ctx, -1, "marl_sweep_radau_dev: at most 65535 instances per call");
+    const int64_t N = ctx->N, n = NF * N, B = ctx->batch;
+    if (n > 8192) return fail(ctx, -1, "marl_sweep_radau_dev: sweeps are for small grids (N <= 1638); use marl_integrate_radau for one large grid");
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    rtol = clamp_rtol(rtol);
+    RadauWork w;
+    int64_t zs = 0;
+    if (int rc = radau_alloc(ctx, w, groups, B, &zs)) return rc;
+    using radau::RadauCtl;
+    // controllers, monitors records, the running counter
+    RadauCtl* dctl = nullptr;
+    double* drec = nullptr;
+    int32_t* drun = nullptr;
+    HIP_OK(ctx, hipMalloc((void**)&dctl, sizeof(RadauCtl) * B));
+    HIP_OK(ctx, hipMalloc((void**)&drec, sizeof(double) * NQ * B));
+    HIP_OK(ctx, hipMalloc((void**)&drun, sizeof(int32_t)));
+    auto cleanup = [&]() { (void)hipFree(dctl); (void)hipFree(drec); (void)hipFree(drun); };
+    std::vector<RadauCtl> hctl((size_t)B);
+    for (auto& c : hctl) {
+        memset(&c, 0, sizeof c);
+        c.t_bound = t1; c.rtol = rtol; c.atol = atol; c.max_attempts = max_attempts;
+        c.newton_tol = std::fmax(10 * radau::EPS / rtol, std::fmin(0.03, std::sqrt(rtol)));
+        c.t = t0; c.S_h_abs = first_step; c.S_h_abs_old = -1; c.S_err_old = -1;
+        c.pc = radau::PC_INIT; c.status = 1;
+    }
+    if (hipMemcpyAsync(dctl, hctl.data(), sizeof(RadauCtl) * B, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { cleanup(); return fail(ctx, -3, "copy failed"); }
+    if (hipMemcpy2DAsync(w.y, (size_t)zs, y_dev, n * sizeof(double), n * sizeof(double), (size_t)B, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+        cleanup();
+        return fail(ctx, -3, "state copy failed");
+    }
+    const double S6 = std::sqrt(6.0);
+    const double E3[3] = {(-13 - 7 * S6) / 3, (-13 + 7 * S6) / 3, -1.0 / 3};
+    const radau::P33 P = {{{13.0 / 3 + 7 * S6 / 3, -23.0 / 3 - 22 * S6 / 3, 10.0 / 3 + 5 * S6},
+                           {13.0 / 3 - 7 * S6 / 3, -23.0 / 3 + 22 * S6 / 3, 10.0 / 3 - 5 * S6},
+                           {1.0 / 3, -8.0 / 3, 10.0 / 3}}};
+    const int32_t* act0 = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(dctl) + offsetof(RadauCtl, action));
+    auto Z = [&](int want) { return ZBatch{zs, act0, (int64_t)sizeof(RadauCtl), want}; };
+    const unsigned Bz = (unsigned)B;
+    const dim3 b256(256);
+    const unsigned gx = blocks256(n), gc = blocks256(N);
+    const cplx c0 = {0, 0};
+    const int64_t nbm = std::min<int64_t>((N + 255) / 256, 1024);
+    if (int rc = ensure_part(ctx, (size_t)(nbm * B))) { cleanup(); return rc; }
+    int rc_out = 0;
+    int32_t* hrun = reinterpret_cast<int32_t*>(ctx->rd_host);
+    const int check_every = 8;
+    using namespace radau;
+#define RB_OK()                                                                                       \
+    do {                                                                                              \
+        hipError_t e_ = hipGetLastError();                                                            \
+        if (e_ != hipSuccess) { cleanup(); return fail(ctx, -100 - (int)e_, "kernel launch failed: %s", hipGetErrorString(e_)); } \
+    } while (0)
+    for (int64_t cycle = 0;; cycle++) {
+        const bool check = (cycle % check_every) == check_every - 1;
+        if (check) (void)hipMemsetAsync(drun, 0, sizeof(int32_t), ctx->stream);
+        hipLaunchKernelGGL(radau_control_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, ctx->stream, dctl, drec, B, n, drun);
+        RB_OK();
+        if (check) {
+            (void)hipMemcpyAsync(hrun, drun, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess) { cleanup(); return fail(ctx, -3, "synchronize failed"); }
+            if (*hrun == 0) break;
+        }
+        // a single state -> its derivative: y -> f (start), y + err -> tmp (second error estimate), y_new -> f_new (accepted step)
+        if (ctx->var_dphi)
+            hipLaunchKernelGGL((rhs_pick_kernel<LAYOUT_FIELD_MAJOR, true>), dim3(gc, 1, Bz), b256, 0, ctx->stream, w.y, w.f, w.yerr, w.tmp, w.ynew, w.fnew, ctx->dconsts,
+                               ctx->slab, Z(A_RHS_Y | A_ERR2 | A_ACCEPT));
+        else
+            hipLaunchKernelGGL((rhs_pick_kernel<LAYOUT_FIELD_MAJOR, false>), dim3(gc, 1, Bz), b256, 0, ctx->stream, w.y, w.f, w.yerr, w.tmp, w.ynew, w.fnew, ctx->dconsts,
+                               ctx->slab, Z(A_RHS_Y | A_ERR2 | A_ACCEPT));
+        RB_OK();
+        hipLaunchKernelGGL(accept_kernel, dim3(gx, 1, Bz), b256, 0, ctx->stream, w.Z, w.Q, w.y, w.yold, w.ynew, w.f, w.fnew, n, P, Z(A_ACCEPT));
+        RB_OK();
+        // monitors of every instance's y (the controller reads them after the start and after each accepted step)
+        hipLaunchKernelGGL(monitors_kernel<LAYOUT_FIELD_MAJOR>, dim3((unsigned)nbm, Bz), b256, 0, ctx->stream, w.y, ctx->dconsts, ctx->slab, zs / 8, ctx->part);
+        RB_OK();
+        hipLaunchKernelGGL(reduce_records_kernel, dim3(Bz), b256, 0, ctx->stream, ctx->part, nbm, drec);
+        RB_OK();
+        // finite-difference Jacobian at (y, f)
+        hipLaunchKernelGGL(fd_prepare_kernel, dim3(gx, 1, Bz), b256, 0, ctx->stream, w.y, w.f, w.fac, atol, 0, w.groups, w.ng, n, w.h, w.yscale, w.YP, Z(A_JAC));
+        RB_OK();
+        for (int pass = 0; pass < 2; pass++) {
+            if (ctx->var_dphi)
+                hipLaunchKernelGGL((rhs_kernel<LAYOUT_FIELD_MAJOR, true>), dim3(gc, (unsigned)w.ng, Bz), b256, 0, ctx->stream, w.YP, w.FN, ctx->dconsts, ctx->slab, n, 0, Z(A_JAC));
+            else
+                hipLaunchKernelGGL(rhs_kernel<LAYOUT_FIELD_MAJOR>, dim3(gc, (unsigned)w.ng, Bz), b256, 0, ctx->stream, w.YP, w.FN, ctx->dconsts, ctx->slab, n, 0, Z(A_JAC));
+            RB_OK();
+            if (pass == 0)
+                hipLaunchKernelGGL(fd_columns_kernel, dim3(gx, 1, Bz), b256, 0, ctx->stream, w.y, w.f, w.FN, w.groups, w.ng, N, w.fac, w.yscale, w.Jraw, w.maxdiff, w.scl,
+                                   w.small, w.hnew, w.YP, Z(A_JAC));
+            else
+                hipLaunchKernelGGL(fd_finish_kernel, dim3(gx, 1, Bz), b256, 0, ctx->stream, w.f, w.FN, w.groups, N, w.fac, w.h, w.maxdiff, w.scl, w.small, w.hnew, w.Jraw,
+                                   w.J, Z(A_JAC));
+            RB_OK();
+        }
+        // factorisations
+        for (int level = -1; level < w.nlevels; level++) {
+            hipLaunchKernelGGL(pcr_factor_kernel, dim3((unsigned)((N + PCR_CELLS_PER_BLOCK - 1) / PCR_CELLS_PER_BLOCK), 2, Bz), b256, 0, ctx->stream, w.J, N, level, 0.0, c0,
+                               w.Sr, w.Sc, Z(A_LU));
+            RB_OK();
+        }
+        // one Newton iteration
+        hipLaunchKernelGGL(newton_begin_batch_kernel, dim3(gx, 1, Bz), b256, 0, ctx->stream, w.y, w.Q, w.yold, n, w.scale, w.Z, w.W, w.YS, Z(A_NEWTON));
+        RB_OK();
+        if (ctx->var_dphi)
+            hipLaunchKernelGGL((rhs_kernel<LAYOUT_FIELD_MAJOR, true>), dim3(gc, 3, Bz), b256, 0, ctx->stream, w.YS, w.F, ctx->dconsts, ctx->slab, n, 0, Z(A_NEWTON));
+        else
+            hipLaunchKernelGGL(rhs_kernel<LAYOUT_FIELD_MAJOR>, dim3(gc, 3, Bz), b256, 0, ctx->stream, w.YS, w.F, ctx->dconsts, ctx->slab, n, 0, Z(A_NEWTON));
+        RB_OK();
+        hipLaunchKernelGGL(newton_rhs_batch_kernel, dim3(gx, 1, Bz), b256, 0, ctx->stream, w.F, w.W, N, w.rhs_r, w.rhs_c, dctl, Z(A_NEWTON));
+        RB_OK();
+        for (int which = 0; which < 2; which++) {   // 0: both systems of the Newton iteration; 1: the real system of the error estimate
+            const int want = which == 0 ? A_NEWTON : (A_ERR | A_ERR2);
+            if (which == 1) {
+                hipLaunchKernelGGL(error_rhs_batch_kernel, dim3(gx, 1, Bz), b256, 0, ctx->stream, w.f, w.tmp, w.Z, w.y, N, E3[0], E3[1], E3[2], w.rhs_r, w.ynew, Z(want));
+                RB_OK();
+            }
+            const double* in_r = w.rhs_r;
+            const cplx* in_c = w.rhs_c;
+            for (int level = 0; level <= w.nlevels; level++) {
+                double* out_r = (level == w.nlevels) ? w.rhs_r : w.Sr.b[level & 1];
+                cplx* out_c = (level == w.nlevels) ? w.rhs_c : w.Sc.b[level & 1];
+                hipLaunchKernelGGL(pcr_solve_kernel, dim3(gx, which == 0 ? 2 : 1, Bz), b256, 0, ctx->stream, N, level, w.nlevels, 0, w.Sr, w.Sc, in_r, out_r, in_c, out_c, Z(want));
+                RB_OK();
+                in_r = out_r;
+                in_c = out_c;
+            }
+            if (which == 0)
+                hipLaunchKernelGGL(newton_update_batch_kernel, dim3(1, 1, Bz), dim3(1024), 0, ctx->stream, w.y, w.rhs_r, w.rhs_c, w.scale, N, w.W, w.Z, w.YS, dctl, Z(want));
+            else
+                hipLaunchKernelGGL(error_norm_batch_kernel, dim3(1, 1, Bz), dim3(1024), 0, ctx->stream, w.rhs_r, w.y, w.ynew, N, w.err, w.yerr, dctl, Z(want));
+            RB_OK();
+        }
+    }
+#undef RB_OK
+    // results
+    if (hipMemcpy2DAsync(y_dev, n * sizeof(double), w.y, (size_t)zs, n * sizeof(double), (size_t)B, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+        rc_out = fail(ctx, -3, "state copy failed");
+    if (rc_out == 0 && hipMemcpyAsync(hctl.data(), dctl, sizeof(RadauCtl) * B, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc_out = fail(ctx, -3, "copy failed");
+    if (rc_out == 0 && hipStreamSynchronize(ctx->stream) != hipSuccess) rc_out = fail(ctx, -3, "synchronize failed");
+    if (rc_out == 0)
+        for (int64_t b = 0; b < B; b++) {
+            const RadauCtl& c = hctl[(size_t)b];
+            marl_stats& st = stats[b];
+            memset(&st, 0, sizeof st);
+            st.nfev = c.nfev; st.njev = c.njev; st.nlu = c.nlu; st.n_accepted = c.n_acc; st.n_rejected = c.n_rej;
+            st.status = c.status; st.t = c.t; st.h_next = c.S_h_abs;
+            for (int e = 0; e < 7; e++) { st.event_value[e] = c.g[e]; st.n_events[e] = c.n_events[e]; }
+        }
+    cleanup();
+    return rc_out;
 }
 
 #endif  // MARL_LAB

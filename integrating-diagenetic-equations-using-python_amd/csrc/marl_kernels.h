@@ -17,6 +17,8 @@
 //   TILED        y[(i>>6)*320 + f*64 + (i&63)]       five 512-byte field rows interleaved per 64-cell
 //                                                    tile: one window = one contiguous 40*WIN-byte run
 #pragma once
+#include <type_traits>
+
 #include "marl_math.h"
 
 namespace marl {
@@ -204,17 +206,39 @@ __device__ __forceinline__ void block_reduce(double (&q)[NQ], double* scratch)
 // Stand-alone RHS: dydt = f(y).  The drop-in for the reference's fun / fun_numba callable
 // (marlpde/LHeureux_model.py:162, :290).  One thread per cell, neighbours straight from L1/L2.
 // ---------------------------------------------------------------------------------------------
+// Batches of instances that each follow their own control flow (the batched implicit path): blockIdx.z = instance, whose data
+// sit `zstride` BYTES behind instance 0's, and whose 32-bit action word (at act + z * act_stride bytes) says what it needs in this
+// cycle: a kernel launched for the actions `want` (a bit mask) returns at once for every other instance.  act == NULL: no masking.
+struct ZBatch {
+    int64_t zstride;
+    const int32_t* act;
+    int64_t act_stride;
+    int want;
+};
+__device__ __forceinline__ bool z_masked_out(const ZBatch& B)
+{
+    return B.act && !(*reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(B.act) + (int64_t)blockIdx.z * B.act_stride) & B.want);
+}
+template <class P>
+__device__ __forceinline__ P* z_shift(P* p, const ZBatch& B)
+{
+    return reinterpret_cast<P*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<P>::type*>(p)) + (int64_t)blockIdx.z * B.zstride);
+}
+
 // blockIdx.y: instance (state at y + blockIdx.y * inst_stride, constants consts[blockIdx.y * const_stride]; const_stride = 0:
-// several states of ONE model - the stage states / finite-difference columns of the implicit path)
+// several states of ONE model - the stage states / finite-difference columns of the implicit path); blockIdx.z: ZBatch instance
+// (constants consts[blockIdx.z] then)
 template <int LAYOUT, bool VD = false>
 __global__ void __launch_bounds__(256) rhs_kernel(const double* __restrict__ y, double* __restrict__ dydt,
-                                                  const DevConsts* __restrict__ consts, Slab S, int64_t inst_stride, int const_stride)
+                                                  const DevConsts* __restrict__ consts, Slab S, int64_t inst_stride, int const_stride,
+                                                  ZBatch B = ZBatch{0, nullptr, 0, 0})
 {
+    if (z_masked_out(B)) return;
     __shared__ double tabs[TABLE_DOUBLES];
     const Tables T = load_tables(tabs, 256);
-    const DevConsts& C = consts[blockIdx.y * const_stride];
-    y += blockIdx.y * inst_stride;
-    dydt += blockIdx.y * inst_stride;
+    const DevConsts& C = consts[blockIdx.y * const_stride + blockIdx.z];
+    y = z_shift(y, B) + blockIdx.y * inst_stride;
+    dydt = z_shift(dydt, B) + blockIdx.y * inst_stride;
     const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (l < S.out_lo || l >= S.out_hi) return;
     const int64_t g = l + S.goff;

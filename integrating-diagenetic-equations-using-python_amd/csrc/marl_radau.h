@@ -41,6 +41,36 @@ __device__ inline cplx recip(cplx a) { const double d = 1.0 / (a.re * a.re + a.i
 __device__ inline double lift(double a, double) { return a; }
 __device__ inline cplx lift(double a, cplx) { return {a, 0.0}; }
 
+// Batched sweeps of Radau instances (marl_radau_batch.h): every instance follows its own control flow, advanced one ACTION per
+// cycle by a device-side controller; the kernels below serve the single-instance driver (ctl == NULL, scalar arguments) and the
+// batched one (blockIdx.z = instance; per-instance scalars from ctl[z]; ZBatch masks out instances that need something else).
+enum : int32_t { A_RHS_Y = 1, A_JAC = 2, A_LU = 4, A_NEWTON = 8, A_ERR = 16, A_ACCEPT = 32, A_ERR2 = 64 };
+struct RadauCtl {
+    // set once
+    double t_bound, rtol, atol, newton_tol;
+    int64_t max_attempts;
+    // Radau._step_impl state (radau.py:404-537); a value < 0 in *_old / *_o encodes None
+    double t, S_h_abs, S_h_abs_old, S_err_old, h_abs, h_abs_o, err_o, min_step, h, t_new;
+    double rate, dW_norm_old, error_norm, safety, factor;
+    double sol_t_old, sol_h;
+    double g[7];
+    int64_t n_events[7];
+    int64_t nfev, njev, nlu, n_acc, n_rej, attempts;
+    // what the data-parallel kernels of this cycle read
+    double mu_r, mu_c_re, mu_c_im;   // MU_REAL / h, MU_COMPLEX / h
+    double x3[3];                    // dense-output abscissae of the three collocation points (Z0 prediction)
+    int32_t action;                  // A_* bits: what this instance needs in this cycle (0: nothing - finished)
+    int32_t pc, status;
+    int32_t current_jac, have_lu, have_sol, have_factor, rejected, k, n_iter, recompute_jac, newton_begin, err_second;
+    // results the kernels leave for the controller
+    double sumsq;                    // sum of squares of the last norm kernel
+    int32_t nonfinite, pad;
+};
+__device__ __forceinline__ const RadauCtl* ctl_of(const ZBatch& B)
+{
+    return reinterpret_cast<const RadauCtl*>(reinterpret_cast<const char*>(B.act) - offsetof(RadauCtl, action) + (int64_t)blockIdx.z * B.act_stride);
+}
+
 // cell-major index kk = 5 i + f  <->  field-major index f N + i
 __device__ __forceinline__ int64_t to_field_major(int64_t kk, int64_t N) { return (kk % NF) * N + kk / NF; }
 
@@ -51,8 +81,12 @@ __device__ __forceinline__ bool in_pattern(int f, int fp) { return !(f < 2 && fp
 // step sizes + the perturbed state of every group:  YP[g][j] = y[j] + (groups[j] == g ? h[j] : 0)
 __global__ void __launch_bounds__(256) fd_prepare_kernel(const double* __restrict__ y, const double* __restrict__ f0, double* __restrict__ factor,
                                                          double threshold, int first, const int32_t* __restrict__ groups, int ng, int64_t n,
-                                                         double* __restrict__ h, double* __restrict__ yscale, double* __restrict__ YP)
+                                                         double* __restrict__ h, double* __restrict__ yscale, double* __restrict__ YP,
+                                                         ZBatch B = ZBatch{0, nullptr, 0, 0})
 {
+    if (z_masked_out(B)) return;
+    if (B.act) first = !ctl_of(B)->have_factor;
+    y = z_shift(y, B); f0 = z_shift(f0, B); factor = z_shift(factor, B); h = z_shift(h, B); yscale = z_shift(yscale, B); YP = z_shift(YP, B);
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     double fac = first ? sqrt(EPS) : factor[j];
@@ -95,8 +129,11 @@ __global__ void __launch_bounds__(256) fd_columns_kernel(const double* __restric
                                                          const int32_t* __restrict__ groups, int ng, int64_t N, const double* __restrict__ factor,
                                                          const double* __restrict__ yscale, double* __restrict__ Jraw, double* __restrict__ maxdiff,
                                                          double* __restrict__ scl, int32_t* __restrict__ small, double* __restrict__ hnew,
-                                                         double* __restrict__ YP2)
+                                                         double* __restrict__ YP2, ZBatch B = ZBatch{0, nullptr, 0, 0})
 {
+    if (z_masked_out(B)) return;
+    y = z_shift(y, B); f0 = z_shift(f0, B); FN = z_shift(FN, B); factor = z_shift(factor, B); yscale = z_shift(yscale, B); Jraw = z_shift(Jraw, B);
+    maxdiff = z_shift(maxdiff, B); scl = z_shift(scl, B); small = z_shift(small, B); hnew = z_shift(hnew, B); YP2 = z_shift(YP2, B);
     const int64_t n = NF * N;
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
@@ -125,8 +162,11 @@ __global__ void __launch_bounds__(256) fd_columns_kernel(const double* __restric
 __global__ void __launch_bounds__(256) fd_finish_kernel(const double* __restrict__ f0, const double* __restrict__ FN2, const int32_t* __restrict__ groups,
                                                         int64_t N, double* __restrict__ factor, double* __restrict__ h, const double* __restrict__ maxdiff,
                                                         const double* __restrict__ scl, const int32_t* __restrict__ small, const double* __restrict__ hnew,
-                                                        const double* __restrict__ Jraw, double* __restrict__ J)
+                                                        const double* __restrict__ Jraw, double* __restrict__ J, ZBatch B = ZBatch{0, nullptr, 0, 0})
 {
+    if (z_masked_out(B)) return;
+    f0 = z_shift(f0, B); FN2 = z_shift(FN2, B); factor = z_shift(factor, B); h = z_shift(h, B); maxdiff = z_shift(maxdiff, B); scl = z_shift(scl, B);
+    small = z_shift(small, B); hnew = z_shift(hnew, B); Jraw = z_shift(Jraw, B); J = z_shift(J, B);
     const int64_t n = NF * N;
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
@@ -314,6 +354,15 @@ struct PcrSystem {
     T* b[2];                                 // ping-pong right-hand sides, cell-major
 };
 
+template <class T>
+__device__ __forceinline__ PcrSystem<T> z_shift_system(PcrSystem<T> S, const ZBatch& B)
+{
+#pragma unroll
+    for (int k = 0; k < 2; k++) { S.L[k] = z_shift(S.L[k], B); S.D[k] = z_shift(S.D[k], B); S.U[k] = z_shift(S.U[k], B); S.Dinv[k] = z_shift(S.Dinv[k], B); S.b[k] = z_shift(S.b[k], B); }
+    S.alpha = z_shift(S.alpha, B); S.gamma = z_shift(S.gamma, B);
+    return S;
+}
+
 // Factorisation with ONE LANE PER BLOCK ELEMENT: a cell's 5 x 5 blocks are spread over 25 lanes of a 32-lane group (8 cells per
 // 256-thread workgroup); block products and the Gauss-Jordan inverse read their operands' rows / columns from a small LDS stage.
 // (The first version gave a whole cell to one lane - ~250 live complex values, 1.7 KB of scratch, 73 us per level at N = 200, 73 % of
@@ -432,8 +481,11 @@ __device__ void pcr_factor_group(const double* __restrict__ J, int64_t N, int le
 
 // blockIdx.y: 0 real system, 1 complex system.  level < 0: initialise from J.
 __global__ void __launch_bounds__(256) pcr_factor_kernel(const double* __restrict__ J, int64_t N, int level, double mu_r, cplx mu_c, PcrSystem<double> Sr,
-                                                         PcrSystem<cplx> Sc)
+                                                         PcrSystem<cplx> Sc, ZBatch B = ZBatch{0, nullptr, 0, 0})
 {
+    if (z_masked_out(B)) return;
+    if (B.act) { const RadauCtl* c = ctl_of(B); mu_r = c->mu_r; mu_c = cplx{c->mu_c_re, c->mu_c_im}; }
+    J = z_shift(J, B); Sr = z_shift_system(Sr, B); Sc = z_shift_system(Sc, B);
     __shared__ PcrStage<cplx> stage[PCR_CELLS_PER_BLOCK];   // (the real system uses the same bytes)
     const int g = threadIdx.x >> 5;
     if (blockIdx.y == 0) pcr_factor_group<double>(J, N, level, mu_r, Sr, *reinterpret_cast<PcrStage<double>*>(&stage[g]));
@@ -472,8 +524,11 @@ __device__ __forceinline__ void pcr_solve_row(int64_t N, int64_t kk, int level, 
 // one level of a solve (level == nlevels: the final D^-1 b); blockIdx.y + first: which system (0 real, 1 complex)
 __global__ void __launch_bounds__(256) pcr_solve_kernel(int64_t N, int level, int nlevels, int first, PcrSystem<double> Sr, PcrSystem<cplx> Sc,
                                                         const double* __restrict__ bin_r, double* __restrict__ bout_r, const cplx* __restrict__ bin_c,
-                                                        cplx* __restrict__ bout_c)
+                                                        cplx* __restrict__ bout_c, ZBatch B = ZBatch{0, nullptr, 0, 0})
 {
+    if (z_masked_out(B)) return;
+    Sr = z_shift_system(Sr, B); Sc = z_shift_system(Sc, B);
+    bin_r = z_shift(bin_r, B); bout_r = z_shift(bout_r, B); bin_c = z_shift(bin_c, B); bout_c = z_shift(bout_c, B);
     const int64_t kk = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (kk >= NF * N) return;
     if (blockIdx.y + first == 0) pcr_solve_row<double>(N, kk, level, nlevels, Sr, bin_r, bout_r);

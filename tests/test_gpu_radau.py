@@ -26,6 +26,13 @@ pytestmark = pytest.mark.gpu
 STATE_TOL = 5e-6   # observed 1.1e-6 (Scenario A, T* = 13 190 yr, 41 steps); see the module docstring
 
 
+@pytest.fixture(scope="module")
+def torch_cuda_radau():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
 def _model(name):
     from dataclasses import asdict
     from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
@@ -128,3 +135,41 @@ def test_radau_api_errors_and_budget(oracle):
     y, st, *_ = oracle.radau(oracle.params_from_dict(p), 200, g["y0"], 0.0, 1.0, 1e-6, 1e-3, 1e-3, max_attempts=5)
     assert res.status == 2 == st.status and res.n_accepted == st.n_accepted and res.t_reached == pytest.approx(st.t, rel=1e-9)
     eq.close()
+
+
+def test_radau_sweep_equals_instance_by_instance(torch_cuda_radau, oracle):
+    """A sweep of Radau integrations (marl_sweep_radau_dev: per-instance step logic as a state machine on the device, all
+    instances advanced together) against the same instances integrated one at a time: the three scenarios of the reference's
+    tests plus variations of the knobs they turn (Phi0, PhiIni, k3 = k4)."""
+    torch = torch_cuda_radau
+    from dataclasses import asdict
+    from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
+    from marlpde_amd.parameters import Map_Scenario
+    N = 200
+    base = asdict(Map_Scenario()) | {"N": N}
+    inst = [{"Phi0": 0.6, "PhiIni": 0.5, "PhiNR": 0.6},                                   # Scenario A
+            {"Phi0": 0.5, "PhiIni": 0.5, "PhiNR": 0.5, "k3": 0.01, "k4": 0.01},         # the Matlab cross-check case
+            {"Phi0": 0.7, "PhiIni": 0.6, "PhiNR": 0.6},
+            {"Phi0": 0.55, "PhiIni": 0.55, "PhiNR": 0.55, "k3": 0.03, "k4": 0.03},
+            {"Phi0": 0.65, "PhiIni": 0.5, "PhiNR": 0.5, "k3": 0.05, "k4": 0.05},
+            {"Phi0": 0.6, "PhiIni": 0.6, "PhiNR": 0.6}]
+    y0 = np.stack([np.concatenate([np.full(N, (base | d)[k]) for k in ("CAIni", "CCIni", "cCaIni", "cCO3Ini", "PhiIni")]) for d in inst])
+    eq = LMAHeureuxPorosityDiff.from_scenario(base, device=0, instances=inst)
+    eq.use_stream(torch.cuda.current_stream().cuda_stream)
+    yd = torch.from_numpy(y0).cuda()
+    res = eq.sweep_radau_device(yd.data_ptr(), (0.0, 1.0), 1e-6, 1e-3, 1e-3)
+    got = yd.cpu().numpy()
+    eq.close()
+    for b, d in enumerate(inst):
+        one = LMAHeureuxPorosityDiff.from_scenario(base | d, device=0)
+        ref = one.integrate_radau(y0[b], (0.0, 1.0), 1e-6, 1e-3, 1e-3)
+        one.close()
+        print(b, (res[b].nfev, res[b].njev, res[b].nlu, res[b].n_accepted), (ref.nfev, ref.njev, ref.nlu, ref.n_accepted))
+        assert res[b].status == 0 == ref.status and res[b].t_reached == 1.0
+        assert _close_counts(res[b], ref.nfev, ref.njev, ref.nlu, ref.n_accepted)
+        same = (res[b].nfev, res[b].njev, res[b].nlu, res[b].n_accepted) == (ref.nfev, ref.njev, ref.nlu, ref.n_accepted)
+        assert np.max(np.abs(got[b] - ref.y_final)) <= (STATE_TOL if same else 2e-3)
+        assert list(res[b].n_events) == [len(e) for e in ref.t_events]
+    # the first two are the reference's regression cases: final profiles within its tolerances of its HDF5 data
+    gold = np.load(f"{GOLDEN}/ref_final_scenarioA_Phi0_0.6_PhiIni_0.5.npy")
+    np.testing.assert_allclose(got[0].reshape(5, N), gold, rtol=0.1, atol=0.01)
