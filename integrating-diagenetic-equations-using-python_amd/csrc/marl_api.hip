@@ -1697,14 +1697,15 @@ extern "C" int marl_sweep_radau_dev(marl_ctx* ctx, double* y_dev, double t0, dou
     int64_t zs = 0;
     if (int rc = radau_alloc(ctx, w, groups, B, &zs)) return rc;
     using radau::RadauCtl;
-    // controllers, monitors records, the running counter
+    // controllers, monitors records, work lists + their counts
     RadauCtl* dctl = nullptr;
     double* drec = nullptr;
-    int32_t* drun = nullptr;
+    int32_t* dcounts = nullptr;   // [L_COUNT] then lists [L_COUNT][B]
     HIP_OK(ctx, hipMalloc((void**)&dctl, sizeof(RadauCtl) * B));
     HIP_OK(ctx, hipMalloc((void**)&drec, sizeof(double) * NQ * B));
-    HIP_OK(ctx, hipMalloc((void**)&drun, sizeof(int32_t)));
-    auto cleanup = [&]() { (void)hipFree(dctl); (void)hipFree(drec); (void)hipFree(drun); };
+    HIP_OK(ctx, hipMalloc((void**)&dcounts, sizeof(int32_t) * (size_t)(radau::L_COUNT * (B + 1))));
+    int32_t* dlists = dcounts + radau::L_COUNT;
+    auto cleanup = [&]() { (void)hipFree(dctl); (void)hipFree(drec); (void)hipFree(dcounts); };
     std::vector<RadauCtl> hctl((size_t)B);
     for (auto& c : hctl) {
         memset(&c, 0, sizeof c);
@@ -1718,22 +1719,22 @@ extern "C" int marl_sweep_radau_dev(marl_ctx* ctx, double* y_dev, double t0, dou
         cleanup();
         return fail(ctx, -3, "state copy failed");
     }
+    (void)hipMemsetAsync(drec, 0, sizeof(double) * NQ * B, ctx->stream);
     const double S6 = std::sqrt(6.0);
     const double E3[3] = {(-13 - 7 * S6) / 3, (-13 + 7 * S6) / 3, -1.0 / 3};
     const radau::P33 P = {{{13.0 / 3 + 7 * S6 / 3, -23.0 / 3 - 22 * S6 / 3, 10.0 / 3 + 5 * S6},
                            {13.0 / 3 - 7 * S6 / 3, -23.0 / 3 + 22 * S6 / 3, 10.0 / 3 - 5 * S6},
                            {1.0 / 3, -8.0 / 3, 10.0 / 3}}};
     const int32_t* act0 = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(dctl) + offsetof(RadauCtl, action));
-    auto Z = [&](int want) { return ZBatch{zs, act0, (int64_t)sizeof(RadauCtl), want}; };
-    const unsigned Bz = (unsigned)B;
+    // a launch over the instances of work list `which` (no action mask needed: the list IS the mask)
+    auto Z = [&](int which) { return ZBatch{zs, act0, (int64_t)sizeof(RadauCtl), ~0, dlists + (int64_t)which * B}; };
     const dim3 b256(256);
     const unsigned gx = blocks256(n), gc = blocks256(N);
     const cplx c0 = {0, 0};
     const int64_t nbm = std::min<int64_t>((N + 255) / 256, 1024);
     if (int rc = ensure_part(ctx, (size_t)(nbm * B))) { cleanup(); return rc; }
     int rc_out = 0;
-    int32_t* hrun = reinterpret_cast<int32_t*>(ctx->rd_host);
-    const int check_every = 8;
+    int32_t* hcounts = reinterpret_cast<int32_t*>(ctx->rd_host);
     using namespace radau;
 #define RB_OK()                                                                                       \
     do {                                                                                              \
@@ -1741,67 +1742,76 @@ extern "C" int marl_sweep_radau_dev(marl_ctx* ctx, double* y_dev, double t0, dou
         if (e_ != hipSuccess) { cleanup(); return fail(ctx, -100 - (int)e_, "kernel launch failed: %s", hipGetErrorString(e_)); } \
     } while (0)
     for (int64_t cycle = 0;; cycle++) {
-        const bool check = (cycle % check_every) == check_every - 1;
-        if (check) (void)hipMemsetAsync(drun, 0, sizeof(int32_t), ctx->stream);
-        hipLaunchKernelGGL(radau_control_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, ctx->stream, dctl, drec, B, n, drun);
+        // the controllers advance every instance to its next piece of work and sort the instances into work lists; the host
+        // reads the list lengths (one small copy + synchronisation per cycle) and launches each kind of work over its list only
+        (void)hipMemsetAsync(dcounts, 0, sizeof(int32_t) * L_COUNT, ctx->stream);
+        hipLaunchKernelGGL(radau_control_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, ctx->stream, dctl, drec, B, n, dcounts, dlists);
         RB_OK();
-        if (check) {
-            (void)hipMemcpyAsync(hrun, drun, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
-            if (hipStreamSynchronize(ctx->stream) != hipSuccess) { cleanup(); return fail(ctx, -3, "synchronize failed"); }
-            if (*hrun == 0) break;
-        }
-        // a single state -> its derivative: y -> f (start), y + err -> tmp (second error estimate), y_new -> f_new (accepted step)
-        if (ctx->var_dphi)
-            hipLaunchKernelGGL((rhs_pick_kernel<LAYOUT_FIELD_MAJOR, true>), dim3(gc, 1, Bz), b256, 0, ctx->stream, w.y, w.f, w.yerr, w.tmp, w.ynew, w.fnew, ctx->dconsts,
-                               ctx->slab, Z(A_RHS_Y | A_ERR2 | A_ACCEPT));
-        else
-            hipLaunchKernelGGL((rhs_pick_kernel<LAYOUT_FIELD_MAJOR, false>), dim3(gc, 1, Bz), b256, 0, ctx->stream, w.y, w.f, w.yerr, w.tmp, w.ynew, w.fnew, ctx->dconsts,
-                               ctx->slab, Z(A_RHS_Y | A_ERR2 | A_ACCEPT));
-        RB_OK();
-        hipLaunchKernelGGL(accept_kernel, dim3(gx, 1, Bz), b256, 0, ctx->stream, w.Z, w.Q, w.y, w.yold, w.ynew, w.f, w.fnew, n, P, Z(A_ACCEPT));
-        RB_OK();
-        // monitors of every instance's y (the controller reads them after the start and after each accepted step)
-        hipLaunchKernelGGL(monitors_kernel<LAYOUT_FIELD_MAJOR>, dim3((unsigned)nbm, Bz), b256, 0, ctx->stream, w.y, ctx->dconsts, ctx->slab, zs / 8, ctx->part);
-        RB_OK();
-        hipLaunchKernelGGL(reduce_records_kernel, dim3(Bz), b256, 0, ctx->stream, ctx->part, nbm, drec);
-        RB_OK();
-        // finite-difference Jacobian at (y, f)
-        hipLaunchKernelGGL(fd_prepare_kernel, dim3(gx, 1, Bz), b256, 0, ctx->stream, w.y, w.f, w.fac, atol, 0, w.groups, w.ng, n, w.h, w.yscale, w.YP, Z(A_JAC));
-        RB_OK();
-        for (int pass = 0; pass < 2; pass++) {
+        (void)hipMemcpyAsync(hcounts, dcounts, sizeof(int32_t) * L_COUNT, hipMemcpyDeviceToHost, ctx->stream);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { cleanup(); return fail(ctx, -3, "synchronize failed"); }
+        if (hcounts[L_RUNNING] == 0) break;
+        const unsigned nR = (unsigned)hcounts[L_RHS1], nA = (unsigned)hcounts[L_ACCEPT], nJ = (unsigned)hcounts[L_JAC], nL = (unsigned)hcounts[L_LU],
+                       nN = (unsigned)hcounts[L_NEWTON], nE = (unsigned)hcounts[L_ERR];
+        if (nR) {   // a single state -> its derivative: y -> f (start), y + err -> tmp (second error estimate), y_new -> f_new (accepted step)
             if (ctx->var_dphi)
-                hipLaunchKernelGGL((rhs_kernel<LAYOUT_FIELD_MAJOR, true>), dim3(gc, (unsigned)w.ng, Bz), b256, 0, ctx->stream, w.YP, w.FN, ctx->dconsts, ctx->slab, n, 0, Z(A_JAC));
+                hipLaunchKernelGGL((rhs_pick_kernel<LAYOUT_FIELD_MAJOR, true>), dim3(gc, 1, nR), b256, 0, ctx->stream, w.y, w.f, w.yerr, w.tmp, w.ynew, w.fnew, ctx->dconsts,
+                                   ctx->slab, Z(L_RHS1));
             else
-                hipLaunchKernelGGL(rhs_kernel<LAYOUT_FIELD_MAJOR>, dim3(gc, (unsigned)w.ng, Bz), b256, 0, ctx->stream, w.YP, w.FN, ctx->dconsts, ctx->slab, n, 0, Z(A_JAC));
-            RB_OK();
-            if (pass == 0)
-                hipLaunchKernelGGL(fd_columns_kernel, dim3(gx, 1, Bz), b256, 0, ctx->stream, w.y, w.f, w.FN, w.groups, w.ng, N, w.fac, w.yscale, w.Jraw, w.maxdiff, w.scl,
-                                   w.small, w.hnew, w.YP, Z(A_JAC));
-            else
-                hipLaunchKernelGGL(fd_finish_kernel, dim3(gx, 1, Bz), b256, 0, ctx->stream, w.f, w.FN, w.groups, N, w.fac, w.h, w.maxdiff, w.scl, w.small, w.hnew, w.Jraw,
-                                   w.J, Z(A_JAC));
+                hipLaunchKernelGGL((rhs_pick_kernel<LAYOUT_FIELD_MAJOR, false>), dim3(gc, 1, nR), b256, 0, ctx->stream, w.y, w.f, w.yerr, w.tmp, w.ynew, w.fnew, ctx->dconsts,
+                                   ctx->slab, Z(L_RHS1));
             RB_OK();
         }
-        // factorisations
-        for (int level = -1; level < w.nlevels; level++) {
-            hipLaunchKernelGGL(pcr_factor_kernel, dim3((unsigned)((N + PCR_CELLS_PER_BLOCK - 1) / PCR_CELLS_PER_BLOCK), 2, Bz), b256, 0, ctx->stream, w.J, N, level, 0.0, c0,
-                               w.Sr, w.Sc, Z(A_LU));
+        if (nA) {
+            hipLaunchKernelGGL(accept_kernel, dim3(gx, 1, nA), b256, 0, ctx->stream, w.Z, w.Q, w.y, w.yold, w.ynew, w.f, w.fnew, n, P, Z(L_ACCEPT));
             RB_OK();
         }
-        // one Newton iteration
-        hipLaunchKernelGGL(newton_begin_batch_kernel, dim3(gx, 1, Bz), b256, 0, ctx->stream, w.y, w.Q, w.yold, n, w.scale, w.Z, w.W, w.YS, Z(A_NEWTON));
-        RB_OK();
-        if (ctx->var_dphi)
-            hipLaunchKernelGGL((rhs_kernel<LAYOUT_FIELD_MAJOR, true>), dim3(gc, 3, Bz), b256, 0, ctx->stream, w.YS, w.F, ctx->dconsts, ctx->slab, n, 0, Z(A_NEWTON));
-        else
-            hipLaunchKernelGGL(rhs_kernel<LAYOUT_FIELD_MAJOR>, dim3(gc, 3, Bz), b256, 0, ctx->stream, w.YS, w.F, ctx->dconsts, ctx->slab, n, 0, Z(A_NEWTON));
-        RB_OK();
-        hipLaunchKernelGGL(newton_rhs_batch_kernel, dim3(gx, 1, Bz), b256, 0, ctx->stream, w.F, w.W, N, w.rhs_r, w.rhs_c, dctl, Z(A_NEWTON));
-        RB_OK();
+        if (nA || cycle == 0) {   // monitors of every instance's y (read by the controllers after the start and after each accepted step)
+            hipLaunchKernelGGL(monitors_kernel<LAYOUT_FIELD_MAJOR>, dim3((unsigned)nbm, (unsigned)B), b256, 0, ctx->stream, w.y, ctx->dconsts, ctx->slab, zs / 8, ctx->part);
+            RB_OK();
+            hipLaunchKernelGGL(reduce_records_kernel, dim3((unsigned)B), b256, 0, ctx->stream, ctx->part, nbm, drec);
+            RB_OK();
+        }
+        if (nJ) {   // finite-difference Jacobian at (y, f)
+            hipLaunchKernelGGL(fd_prepare_kernel, dim3(gx, 1, nJ), b256, 0, ctx->stream, w.y, w.f, w.fac, atol, 0, w.groups, w.ng, n, w.h, w.yscale, w.YP, Z(L_JAC));
+            RB_OK();
+            for (int pass = 0; pass < 2; pass++) {
+                if (ctx->var_dphi)
+                    hipLaunchKernelGGL((rhs_kernel<LAYOUT_FIELD_MAJOR, true>), dim3(gc, (unsigned)w.ng, nJ), b256, 0, ctx->stream, w.YP, w.FN, ctx->dconsts, ctx->slab, n, 0, Z(L_JAC));
+                else
+                    hipLaunchKernelGGL(rhs_kernel<LAYOUT_FIELD_MAJOR>, dim3(gc, (unsigned)w.ng, nJ), b256, 0, ctx->stream, w.YP, w.FN, ctx->dconsts, ctx->slab, n, 0, Z(L_JAC));
+                RB_OK();
+                if (pass == 0)
+                    hipLaunchKernelGGL(fd_columns_kernel, dim3(gx, 1, nJ), b256, 0, ctx->stream, w.y, w.f, w.FN, w.groups, w.ng, N, w.fac, w.yscale, w.Jraw, w.maxdiff, w.scl,
+                                       w.small, w.hnew, w.YP, Z(L_JAC));
+                else
+                    hipLaunchKernelGGL(fd_finish_kernel, dim3(gx, 1, nJ), b256, 0, ctx->stream, w.f, w.FN, w.groups, N, w.fac, w.h, w.maxdiff, w.scl, w.small, w.hnew, w.Jraw,
+                                       w.J, Z(L_JAC));
+                RB_OK();
+            }
+        }
+        if (nL)
+            for (int level = -1; level < w.nlevels; level++) {
+                hipLaunchKernelGGL(pcr_factor_kernel, dim3((unsigned)((N + PCR_CELLS_PER_BLOCK - 1) / PCR_CELLS_PER_BLOCK), 2, nL), b256, 0, ctx->stream, w.J, N, level, 0.0, c0,
+                                   w.Sr, w.Sc, Z(L_LU));
+                RB_OK();
+            }
+        if (nN) {   // one Newton iteration
+            hipLaunchKernelGGL(newton_begin_batch_kernel, dim3(gx, 1, nN), b256, 0, ctx->stream, w.y, w.Q, w.yold, n, w.scale, w.Z, w.W, w.YS, Z(L_NEWTON));
+            RB_OK();
+            if (ctx->var_dphi)
+                hipLaunchKernelGGL((rhs_kernel<LAYOUT_FIELD_MAJOR, true>), dim3(gc, 3, nN), b256, 0, ctx->stream, w.YS, w.F, ctx->dconsts, ctx->slab, n, 0, Z(L_NEWTON));
+            else
+                hipLaunchKernelGGL(rhs_kernel<LAYOUT_FIELD_MAJOR>, dim3(gc, 3, nN), b256, 0, ctx->stream, w.YS, w.F, ctx->dconsts, ctx->slab, n, 0, Z(L_NEWTON));
+            RB_OK();
+            hipLaunchKernelGGL(newton_rhs_batch_kernel, dim3(gx, 1, nN), b256, 0, ctx->stream, w.F, w.W, N, w.rhs_r, w.rhs_c, dctl, Z(L_NEWTON));
+            RB_OK();
+        }
         for (int which = 0; which < 2; which++) {   // 0: both systems of the Newton iteration; 1: the real system of the error estimate
-            const int want = which == 0 ? A_NEWTON : (A_ERR | A_ERR2);
+            const unsigned cnt = which == 0 ? nN : nE;
+            if (!cnt) continue;
+            const ZBatch zb = Z(which == 0 ? L_NEWTON : L_ERR);
             if (which == 1) {
-                hipLaunchKernelGGL(error_rhs_batch_kernel, dim3(gx, 1, Bz), b256, 0, ctx->stream, w.f, w.tmp, w.Z, w.y, N, E3[0], E3[1], E3[2], w.rhs_r, w.ynew, Z(want));
+                hipLaunchKernelGGL(error_rhs_batch_kernel, dim3(gx, 1, cnt), b256, 0, ctx->stream, w.f, w.tmp, w.Z, w.y, N, E3[0], E3[1], E3[2], w.rhs_r, w.ynew, zb);
                 RB_OK();
             }
             const double* in_r = w.rhs_r;
@@ -1809,15 +1819,15 @@ extern "C" int marl_sweep_radau_dev(marl_ctx* ctx, double* y_dev, double t0, dou
             for (int level = 0; level <= w.nlevels; level++) {
                 double* out_r = (level == w.nlevels) ? w.rhs_r : w.Sr.b[level & 1];
                 cplx* out_c = (level == w.nlevels) ? w.rhs_c : w.Sc.b[level & 1];
-                hipLaunchKernelGGL(pcr_solve_kernel, dim3(gx, which == 0 ? 2 : 1, Bz), b256, 0, ctx->stream, N, level, w.nlevels, 0, w.Sr, w.Sc, in_r, out_r, in_c, out_c, Z(want));
+                hipLaunchKernelGGL(pcr_solve_kernel, dim3(gx, which == 0 ? 2 : 1, cnt), b256, 0, ctx->stream, N, level, w.nlevels, 0, w.Sr, w.Sc, in_r, out_r, in_c, out_c, zb);
                 RB_OK();
                 in_r = out_r;
                 in_c = out_c;
             }
             if (which == 0)
-                hipLaunchKernelGGL(newton_update_batch_kernel, dim3(1, 1, Bz), dim3(1024), 0, ctx->stream, w.y, w.rhs_r, w.rhs_c, w.scale, N, w.W, w.Z, w.YS, dctl, Z(want));
+                hipLaunchKernelGGL(newton_update_batch_kernel, dim3(1, 1, cnt), dim3(1024), 0, ctx->stream, w.y, w.rhs_r, w.rhs_c, w.scale, N, w.W, w.Z, w.YS, dctl, zb);
             else
-                hipLaunchKernelGGL(error_norm_batch_kernel, dim3(1, 1, Bz), dim3(1024), 0, ctx->stream, w.rhs_r, w.y, w.ynew, N, w.err, w.yerr, dctl, Z(want));
+                hipLaunchKernelGGL(error_norm_batch_kernel, dim3(1, 1, cnt), dim3(1024), 0, ctx->stream, w.rhs_r, w.y, w.ynew, N, w.err, w.yerr, dctl, zb);
             RB_OK();
         }
     }

@@ -209,20 +209,24 @@ __device__ __forceinline__ void block_reduce(double (&q)[NQ], double* scratch)
 // Batches of instances that each follow their own control flow (the batched implicit path): blockIdx.z = instance, whose data
 // sit `zstride` BYTES behind instance 0's, and whose 32-bit action word (at act + z * act_stride bytes) says what it needs in this
 // cycle: a kernel launched for the actions `want` (a bit mask) returns at once for every other instance.  act == NULL: no masking.
+// `list` (may be NULL): the launch covers only the instances list[0 .. gridDim.z) - a compacted index list the controller wrote for
+// this kind of work - instead of all of them.
 struct ZBatch {
     int64_t zstride;
     const int32_t* act;
     int64_t act_stride;
     int want;
+    const int32_t* list;
 };
+__device__ __forceinline__ int64_t z_inst(const ZBatch& B) { return B.list ? (int64_t)B.list[blockIdx.z] : (int64_t)blockIdx.z; }
 __device__ __forceinline__ bool z_masked_out(const ZBatch& B)
 {
-    return B.act && !(*reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(B.act) + (int64_t)blockIdx.z * B.act_stride) & B.want);
+    return B.act && !(*reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(B.act) + z_inst(B) * B.act_stride) & B.want);
 }
 template <class P>
 __device__ __forceinline__ P* z_shift(P* p, const ZBatch& B)
 {
-    return reinterpret_cast<P*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<P>::type*>(p)) + (int64_t)blockIdx.z * B.zstride);
+    return reinterpret_cast<P*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<P>::type*>(p)) + z_inst(B) * B.zstride);
 }
 
 // blockIdx.y: instance (state at y + blockIdx.y * inst_stride, constants consts[blockIdx.y * const_stride]; const_stride = 0:
@@ -231,12 +235,12 @@ __device__ __forceinline__ P* z_shift(P* p, const ZBatch& B)
 template <int LAYOUT, bool VD = false>
 __global__ void __launch_bounds__(256) rhs_kernel(const double* __restrict__ y, double* __restrict__ dydt,
                                                   const DevConsts* __restrict__ consts, Slab S, int64_t inst_stride, int const_stride,
-                                                  ZBatch B = ZBatch{0, nullptr, 0, 0})
+                                                  ZBatch B = ZBatch{0, nullptr, 0, 0, nullptr})
 {
     if (z_masked_out(B)) return;
     __shared__ double tabs[TABLE_DOUBLES];
     const Tables T = load_tables(tabs, 256);
-    const DevConsts& C = consts[blockIdx.y * const_stride + blockIdx.z];
+    const DevConsts& C = consts[blockIdx.y * const_stride + z_inst(B)];
     y = z_shift(y, B) + blockIdx.y * inst_stride;
     dydt = z_shift(dydt, B) + blockIdx.y * inst_stride;
     const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;

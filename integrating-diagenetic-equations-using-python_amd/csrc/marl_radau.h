@@ -68,7 +68,7 @@ struct RadauCtl {
 };
 __device__ __forceinline__ const RadauCtl* ctl_of(const ZBatch& B)
 {
-    return reinterpret_cast<const RadauCtl*>(reinterpret_cast<const char*>(B.act) - offsetof(RadauCtl, action) + (int64_t)blockIdx.z * B.act_stride);
+    return reinterpret_cast<const RadauCtl*>(reinterpret_cast<const char*>(B.act) - offsetof(RadauCtl, action) + z_inst(B) * B.act_stride);
 }
 
 // cell-major index kk = 5 i + f  <->  field-major index f N + i
@@ -82,7 +82,7 @@ __device__ __forceinline__ bool in_pattern(int f, int fp) { return !(f < 2 && fp
 __global__ void __launch_bounds__(256) fd_prepare_kernel(const double* __restrict__ y, const double* __restrict__ f0, double* __restrict__ factor,
                                                          double threshold, int first, const int32_t* __restrict__ groups, int ng, int64_t n,
                                                          double* __restrict__ h, double* __restrict__ yscale, double* __restrict__ YP,
-                                                         ZBatch B = ZBatch{0, nullptr, 0, 0})
+                                                         ZBatch B = ZBatch{0, nullptr, 0, 0, nullptr})
 {
     if (z_masked_out(B)) return;
     if (B.act) first = !ctl_of(B)->have_factor;
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(256) fd_columns_kernel(const double* __restric
                                                          const int32_t* __restrict__ groups, int ng, int64_t N, const double* __restrict__ factor,
                                                          const double* __restrict__ yscale, double* __restrict__ Jraw, double* __restrict__ maxdiff,
                                                          double* __restrict__ scl, int32_t* __restrict__ small, double* __restrict__ hnew,
-                                                         double* __restrict__ YP2, ZBatch B = ZBatch{0, nullptr, 0, 0})
+                                                         double* __restrict__ YP2, ZBatch B = ZBatch{0, nullptr, 0, 0, nullptr})
 {
     if (z_masked_out(B)) return;
     y = z_shift(y, B); f0 = z_shift(f0, B); FN = z_shift(FN, B); factor = z_shift(factor, B); yscale = z_shift(yscale, B); Jraw = z_shift(Jraw, B);
@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256) fd_columns_kernel(const double* __restric
 __global__ void __launch_bounds__(256) fd_finish_kernel(const double* __restrict__ f0, const double* __restrict__ FN2, const int32_t* __restrict__ groups,
                                                         int64_t N, double* __restrict__ factor, double* __restrict__ h, const double* __restrict__ maxdiff,
                                                         const double* __restrict__ scl, const int32_t* __restrict__ small, const double* __restrict__ hnew,
-                                                        const double* __restrict__ Jraw, double* __restrict__ J, ZBatch B = ZBatch{0, nullptr, 0, 0})
+                                                        const double* __restrict__ Jraw, double* __restrict__ J, ZBatch B = ZBatch{0, nullptr, 0, 0, nullptr})
 {
     if (z_masked_out(B)) return;
     f0 = z_shift(f0, B); FN2 = z_shift(FN2, B); factor = z_shift(factor, B); h = z_shift(h, B); maxdiff = z_shift(maxdiff, B); scl = z_shift(scl, B);
@@ -481,7 +481,7 @@ __device__ void pcr_factor_group(const double* __restrict__ J, int64_t N, int le
 
 // blockIdx.y: 0 real system, 1 complex system.  level < 0: initialise from J.
 __global__ void __launch_bounds__(256) pcr_factor_kernel(const double* __restrict__ J, int64_t N, int level, double mu_r, cplx mu_c, PcrSystem<double> Sr,
-                                                         PcrSystem<cplx> Sc, ZBatch B = ZBatch{0, nullptr, 0, 0})
+                                                         PcrSystem<cplx> Sc, ZBatch B = ZBatch{0, nullptr, 0, 0, nullptr})
 {
     if (z_masked_out(B)) return;
     if (B.act) { const RadauCtl* c = ctl_of(B); mu_r = c->mu_r; mu_c = cplx{c->mu_c_re, c->mu_c_im}; }
@@ -524,7 +524,7 @@ __device__ __forceinline__ void pcr_solve_row(int64_t N, int64_t kk, int level, 
 // one level of a solve (level == nlevels: the final D^-1 b); blockIdx.y + first: which system (0 real, 1 complex)
 __global__ void __launch_bounds__(256) pcr_solve_kernel(int64_t N, int level, int nlevels, int first, PcrSystem<double> Sr, PcrSystem<cplx> Sc,
                                                         const double* __restrict__ bin_r, double* __restrict__ bout_r, const cplx* __restrict__ bin_c,
-                                                        cplx* __restrict__ bout_c, ZBatch B = ZBatch{0, nullptr, 0, 0})
+                                                        cplx* __restrict__ bout_c, ZBatch B = ZBatch{0, nullptr, 0, 0, nullptr})
 {
     if (z_masked_out(B)) return;
     Sr = z_shift_system(Sr, B); Sc = z_shift_system(Sc, B);

@@ -27,8 +27,13 @@ __device__ __forceinline__ double predict_factor(double h_abs, double h_abs_old,
 }
 
 // One lane per instance: resume the step logic, run it to the next action.  rec: [B][8] monitors records of the instances' y.
+// Work lists: the controller appends each instance to the list of every kernel group that serves its action; counts[L_*] are read by
+// the host, which sizes the launches by them (masked-out workgroups are not free: at 512 instances a cycle that launched every kernel
+// over every instance spent 2.4 ms dispatching ~320 000 workgroups that returned at once).
+enum : int { L_RHS1 = 0, L_ACCEPT, L_JAC, L_LU, L_NEWTON, L_ERR, L_RUNNING, L_COUNT };
+
 __global__ void __launch_bounds__(64) radau_control_kernel(RadauCtl* __restrict__ ctls, const double* __restrict__ rec, int64_t B, int64_t n,
-                                                           int32_t* __restrict__ running)
+                                                           int32_t* __restrict__ counts, int32_t* __restrict__ lists)
 {
     const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
@@ -201,7 +206,14 @@ __global__ void __launch_bounds__(64) radau_control_kernel(RadauCtl* __restrict_
     }
     c.pc = pc;
     ctls[b] = c;
-    if (pc != PC_DONE) atomicAdd(running, 1);
+    if (pc != PC_DONE) atomicAdd(&counts[L_RUNNING], 1);
+    auto push = [&](int which) { lists[(int64_t)which * B + atomicAdd(&counts[which], 1)] = (int32_t)b; };
+    if (c.action & (A_RHS_Y | A_ERR2 | A_ACCEPT)) push(L_RHS1);
+    if (c.action & A_ACCEPT) push(L_ACCEPT);
+    if (c.action & A_JAC) push(L_JAC);
+    if (c.action & A_LU) push(L_LU);
+    if (c.action & A_NEWTON) push(L_NEWTON);
+    if (c.action & (A_ERR | A_ERR2)) push(L_ERR);
 }
 
 // ---- element-wise kernels of the batch (blockIdx.z = instance; scalars from the instance's controller) ---------------------
@@ -217,7 +229,7 @@ __global__ void __launch_bounds__(256) rhs_pick_kernel(const double* y, double* 
     double* dst = z_shift((a & A_RHS_Y) ? f : ((a & A_ERR2) ? tmp : fnew), B);
     __shared__ double tabs[TABLE_DOUBLES];
     const Tables T = load_tables(tabs, 256);
-    const DevConsts& C = consts[blockIdx.z];
+    const DevConsts& C = consts[z_inst(B)];
     const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (l < S.out_lo || l >= S.out_hi) return;
     const int64_t g = l + S.goff;
@@ -296,7 +308,7 @@ __global__ void __launch_bounds__(256) newton_rhs_batch_kernel(const double* __r
     if (kk >= n) return;
     const int64_t i = to_field_major(kk, N);
     const double f0 = F[i], f1 = F[n + i], f2 = F[2 * n + i];
-    if (!(isfinite(f0) && isfinite(f1) && isfinite(f2))) atomicOr(&ctls[blockIdx.z].nonfinite, 1);
+    if (!(isfinite(f0) && isfinite(f1) && isfinite(f2))) atomicOr(&ctls[z_inst(B)].nonfinite, 1);
     rhs_r[kk] = ((f0 * TI00 + f1 * TI01) + f2 * TI02) - c->mu_r * W[i];
     const cplx w = {W[n + i], W[2 * n + i]};
     const cplx fc = {(f0 * TI10 + f1 * TI11) + f2 * TI12, (f0 * TI20 + f1 * TI21) + f2 * TI22};
@@ -332,7 +344,7 @@ __global__ void __launch_bounds__(1024) newton_update_batch_kernel(const double*
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) ctls[blockIdx.z].sumsq = red[0];
+    if (threadIdx.x == 0) ctls[z_inst(B)].sumsq = red[0];
 }
 
 // A_ERR / A_ERR2: right-hand side of the error estimate (f, or f(y + err) in tmp) + Z^T E / h, cell-major; y_new = y + Z[2]
@@ -380,7 +392,7 @@ __global__ void __launch_bounds__(1024) error_norm_batch_kernel(const double* __
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) ctls[blockIdx.z].sumsq = red[0];
+    if (threadIdx.x == 0) ctls[z_inst(B)].sumsq = red[0];
 }
 
 }  // namespace radau
