@@ -55,15 +55,13 @@ __device__ __forceinline__ double nanmax(double a, double b) { return (a > b || 
 // are far outside the expansions' range).  The cache (marl_math.h, PointCache) also needs its LDS slots to fit
 // the 64 KB a workgroup may declare: wide variants (512 threads, several cells per thread) run without it.
 // VD: the time-varying porosity diffusion coefficient (marl_params.dPhi_variable), see marl_math.h.
-// WIDE: the 6th-order tier of the expansions (marl_math.h, REUSE_WIDE) - one-workgroup sweeps on coarse grids, where the centre
-// of the expansions then serves many consecutive steps.
-template <int BLK, int CPT, bool REUSE = true, bool VD = false, bool WIDE = false>
+template <int BLK, int CPT, bool REUSE = true, bool VD = false>
 struct StencilBlock {
     static constexpr int WIN = BLK * CPT;
     static constexpr int NSIDE = (CPT == 1) ? 1 : 2;
     static constexpr int EDGE_DOUBLES = 2 * NSIDE * NF * BLK;       // edges [parity][side][field][thread]
     static constexpr bool CACHE_LDS = PC_LDS_SLOTS > 0;
-    static constexpr bool CACHE = REUSE && (EDGE_DOUBLES + TABLE_DOUBLES + PC_LDS_SLOTS * WIN) * 8 <= (WIDE ? 120 : 60) * 1024;
+    static constexpr bool CACHE = REUSE && (EDGE_DOUBLES + TABLE_DOUBLES + PC_LDS_SLOTS * WIN) * 8 <= 60 * 1024;
     static constexpr int CACHE_DOUBLES = CACHE ? PC_LDS_SLOTS * WIN : 0;
     static constexpr int LDS_DOUBLES = EDGE_DOUBLES + TABLE_DOUBLES + CACHE_DOUBLES;  // edges, log/exp tables, cache slots [slot][cell][thread]
 
@@ -119,7 +117,7 @@ struct StencilBlock {
         PointLocal pl[CPT];
 #pragma unroll
         for (int c = 0; c < CPT; c++) {
-            point_local<CACHE ? MODE : TR_PLAIN, (CACHE && CACHE_LDS) ? WIN : 0, VD, WIDE>(ys[c], (zone_mask >> c) & 1u, K, C, T, pl[c], aux[c], cache[CACHE ? c : 0], reuse_live[c]);
+            point_local<CACHE ? MODE : TR_PLAIN, (CACHE && CACHE_LDS) ? WIN : 0, VD>(ys[c], (zone_mask >> c) & 1u, K, C, T, pl[c], aux[c], cache[CACHE ? c : 0], reuse_live[c]);
             // one cell at a time: interleaving the cells' evaluations doubles the live temporaries (spills at CPT >= 2)
             if constexpr (CPT > 1) __builtin_amdgcn_sched_barrier(0);
         }
@@ -674,9 +672,7 @@ struct DenseWeights { double w[7]; };
 // PARK = number of fields (0..5) of the step's first state y that are NOT held in registers but in this thread's LDS column
 // `pk` (pk[(c*NF + f) * BLK], f < PARK) and re-read where a stage state is formed - up to five live doubles less across every
 // evaluation (kernels that sit just above a register cap: 128 VGPRs = 4 waves per SIMD).
-// FIRST: mode of the K2 evaluation - TR_FILL (a launch starts without a centre) or TR_AUTO (one-workgroup sweeps: the centre
-// survives from attempt to attempt).
-template <int BLK, int CPT, bool DENSE = false, class SB = StencilBlock<BLK, CPT>, int PARK = 0, int FIRST = TR_FILL>
+template <int BLK, int CPT, bool DENSE = false, class SB = StencilBlock<BLK, CPT>, int PARK = 0>
 __device__ __forceinline__ void dp45_attempt(SB& sb, double h,
                                              const double (&y)[CPT][NF], const double (&k1)[CPT][NF],
                                              double (&yn)[CPT][NF], double (&k7)[CPT][NF], double (&esum)[CPT][NF],
@@ -691,7 +687,7 @@ __device__ __forceinline__ void dp45_attempt(SB& sb, double h,
 #define MARL_CELLS _Pragma("unroll") for (int c = 0; c < CPT; c++) _Pragma("unroll") for (int f = 0; f < NF; f++)
 #define MARL_Y(c, f) ((f) < PARK ? pk[((c) * NF + (f)) * BLK] : y[c][f])
     MARL_CELLS ys[c][f] = MARL_Y(c, f) + (k1[c][f] * dp::A21) * h;
-    sb.template eval<FIRST>(ys, k2, aux);
+    sb.template eval<TR_FILL>(ys, k2, aux);
     MARL_CELLS ys[c][f] = MARL_Y(c, f) + (k1[c][f] * dp::A31 + k2[c][f] * dp::A32) * h;
     sb.template eval<TR_REUSE>(ys, k3, aux);
     MARL_CELLS ys[c][f] = MARL_Y(c, f) + (k1[c][f] * dp::A41 + k2[c][f] * dp::A42 + k3[c][f] * dp::A43) * h;
@@ -1015,40 +1011,21 @@ __global__ void __launch_bounds__(256) slab_copy_kernel(double* __restrict__ Y0,
 // on-chip for the whole integration; global memory is touched at entry and exit only.
 //   Y: [batch][5][N] field-major per instance (the reference's layout, one instance after another).
 // ---------------------------------------------------------------------------------------------
-// 1024-thread workgroups (16 waves: 4 per SIMD) cap a thread at 128 VGPRs, which this kernel overruns (38 spilled VGPRs, 156 B
-// of scratch per lane).  Parking the step's first state y in LDS (SWEEP_PARK; dp45_attempt) brings that to 33 - and changes
-// nothing measurable (1.271e10 against 1.278e10): the spill code sits outside the stage loop, 16 scratch operations per attempt
-// against ~2000 VALU instructions per wave.  What bounds this kernel is in DESIGN.md 5 (SQ counters); parking is compiled out.
-#ifndef MARL_SWEEP_PARK
-#define MARL_SWEEP_PARK 0
-#endif
-template <int BLK, int CPT>
-constexpr int SWEEP_PARK = (MARL_SWEEP_PARK != 0 && BLK * CPT >= 1024 && CPT == 1) ? NF : 0;
-// Transcendental reuse in one-workgroup sweeps (wide 6th-order tier of the expansions, centre carried from attempt to attempt)
-// is compiled out: measured on BASELINE config 3 (4096 x N = 1024) it saves 5 % of the VALU instructions only - inside the
-// dissolution zone the solute concentrations move ~1 % per step at this resolution (dt ~ dx^2, rates ~5e4), far outside any
-// short expansion - and costs 8 more spilled VGPRs: 1.25e10 against 1.27e10 (profiles/r02_lab_sweep_experiments.log).
-#ifndef MARL_SWEEP_REUSE
-#define MARL_SWEEP_REUSE 0
-#endif
-template <int CPT>
-constexpr bool SWEEP_REUSE = (CPT == 1) && (MARL_SWEEP_REUSE != 0);
-
+// (1024-thread workgroups cap a thread at 128 VGPRs, which this kernel overruns: 38 spilled VGPRs.  Parking the step's first state in
+// LDS, and a 6th-order reuse tier for coarse grids, were measured and dropped - profiles/r02_lab_sweep_experiments.log)
 template <int BLK, int CPT, bool VD = false>
 __global__ void __launch_bounds__(BLK) rk45_sweep_kernel(double* __restrict__ Y, const DevConsts* __restrict__ consts,
                                                          Rk45Ctrl* __restrict__ ctrls, int64_t N,
                                                          double* __restrict__ Yold, double* __restrict__ Fold)
 {
-    using SB = StencilBlock<BLK, CPT, SWEEP_REUSE<CPT>, VD, true>;
-    constexpr int PARK = SWEEP_PARK<BLK, CPT>;
-    __shared__ double lds[SB::LDS_DOUBLES + (PARK ? CPT * NF * BLK : 0)];
+    using SB = StencilBlock<BLK, CPT, false, VD>;
+    __shared__ double lds[SB::LDS_DOUBLES];
     __shared__ Rk45Ctrl sc;
     const DevConsts& C = consts[blockIdx.x];
     double* yg = Y + (int64_t)blockIdx.x * NF * N;
     Slab S = {N, 0, N, 0, N};
     const int64_t l0 = (int64_t)threadIdx.x * CPT;
     SB sb(lds, l0, consts + blockIdx.x);
-    double* pk = lds + SB::LDS_DOUBLES + threadIdx.x;   // PARK: this thread's column, pk[j * BLK]
     if (threadIdx.x == 0) sc = ctrls[blockIdx.x];
     __syncthreads();
     if (sc.status != ST_RUNNING) return;
@@ -1057,18 +1034,12 @@ __global__ void __launch_bounds__(BLK) rk45_sweep_kernel(double* __restrict__ Y,
     double y[CPT][NF], k1[CPT][NF], yn[CPT][NF], k7[CPT][NF], esum[CPT][NF];
     PointAux aux[CPT];
     load_cells<CPT, LAYOUT_FIELD_MAJOR>(yg, l0, S, C, y);
-    sb.template eval<TR_FILL>(y, k1, aux);  // f(t, y): RungeKutta.__init__ (first launch) or re-derived on resume
-    if constexpr (PARK) {
-#pragma unroll
-        for (int c = 0; c < CPT; c++)
-#pragma unroll
-            for (int f = 0; f < NF; f++) pk[(c * NF + f) * BLK] = y[c][f];
-    }
-#define MARL_Y(c, f) ((f) < PARK ? pk[((c) * NF + (f)) * BLK] : y[c][f])
+    sb.eval(y, k1, aux);  // f(t, y): RungeKutta.__init__ (first launch) or re-derived on resume
+#define MARL_Y(c, f) y[c][f]
 
     while (true) {
         const double h = sc.h_try;
-        dp45_attempt<BLK, CPT, false, SB, PARK, TR_AUTO>(sb, h, y, k1, yn, k7, esum, aux, DenseWeights{}, pk);
+        dp45_attempt<BLK, CPT, false, SB>(sb, h, y, k1, yn, k7, esum, aux);
         double q[NQ];
         monitors_init(q);
 #pragma unroll
@@ -1101,7 +1072,7 @@ __global__ void __launch_bounds__(BLK) rk45_sweep_kernel(double* __restrict__ Y,
             for (int c = 0; c < CPT; c++)
 #pragma unroll
                 for (int f = 0; f < NF; f++) {
-                    if constexpr (PARK) pk[(c * NF + f) * BLK] = yn[c][f]; else y[c][f] = yn[c][f];
+                    y[c][f] = yn[c][f];
                     k1[c][f] = k7[c][f];
                 }
         }
@@ -1126,7 +1097,7 @@ template <int BLK, int CPT, bool VD = false>
 __global__ void __launch_bounds__(BLK) rk4_sweep_kernel(double* __restrict__ Y, const DevConsts* __restrict__ consts,
                                                         const double* __restrict__ dts, int64_t N, int64_t nsteps)
 {
-    using SB = StencilBlock<BLK, CPT, SWEEP_REUSE<CPT>, VD, true>;
+    using SB = StencilBlock<BLK, CPT, false, VD>;
     __shared__ double lds[SB::LDS_DOUBLES];
     const DevConsts& C = consts[blockIdx.x];
     double* yg = Y + (int64_t)blockIdx.x * NF * N;
@@ -1141,7 +1112,7 @@ __global__ void __launch_bounds__(BLK) rk4_sweep_kernel(double* __restrict__ Y, 
 #define MARL_CELLS _Pragma("unroll") for (int c = 0; c < CPT; c++) _Pragma("unroll") for (int f = 0; f < NF; f++)
 #pragma unroll 1
     for (int64_t s = 0; s < nsteps; s++) {
-        sb.template eval<TR_AUTO>(y, k, aux);   // the centre survives from step to step (wide tier)
+        sb.template eval<TR_FILL>(y, k, aux);
         MARL_CELLS { acc[c][f] = k[c][f]; ys[c][f] = y[c][f] + h2 * k[c][f]; }
         sb.template eval<TR_REUSE>(ys, k, aux);
         MARL_CELLS { acc[c][f] = acc[c][f] + 2.0 * k[c][f]; ys[c][f] = y[c][f] + h2 * k[c][f]; }

@@ -199,8 +199,6 @@ struct PointAux {
 // step loop spills at 4 waves per SIMD (scratch reloads in every stage: -25 %); all in LDS, the extra ds_reads
 // cost more than they save (the neighbour exchange already loads the LDS pipe) - profiles/r01_lab_cache_placement.log.
 enum : int { TR_PLAIN = 0, TR_FILL = 1, TR_REUSE = 2, TR_AUTO = 3 };
-constexpr double REUSE_WIDE = 2e-3;    // 6th-order expansions: truncation x^7/7 < 2e-20 (coarse grids / one-workgroup sweeps: the centre
-                                       // then serves many consecutive steps)
 constexpr double REUSE_LIMIT = 5e-5;   // 3rd-order expansions: truncation x^4 < 1e-17
 constexpr double REUSE_TINY = 2e-6;    // below this the 3rd-order terms themselves are < 1e-17: 2nd order suffices
 
@@ -211,20 +209,6 @@ constexpr double REUSE_TINY = 2e-6;    // below this the 3rd-order terms themsel
 enum : int { PC_INVPHI, PC_INVOM, PC_INVDEN, PC_IB, PC_E, PC_TC, PC_SLOTS };
 constexpr int PC_FIRST_LDS = PC_SLOTS - (MARL_CACHE_LDS_SLOTS < PC_SLOTS ? MARL_CACHE_LDS_SLOTS : PC_SLOTS);
 constexpr int PC_LDS_SLOTS = PC_SLOTS - PC_FIRST_LDS;
-
-// 6th-order pieces of the wide tier (|t| < 2e-3):  log1p(t)/t,  1/(1-t),  e^t
-__device__ __forceinline__ double series_log1p6(double t)
-{
-    return __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, -1.0 / 6, 0.2), -0.25), 1.0 / 3), -0.5), 1.0);
-}
-__device__ __forceinline__ double series_geom6(double t)   // 1 + t + ... + t^6
-{
-    return __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, 1.0 + t, 1.0), 1.0), 1.0), 1.0), 1.0);
-}
-__device__ __forceinline__ double series_exp6(double t)
-{
-    return __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, 1.0 / 720, 1.0 / 120), 1.0 / 24), 1.0 / 6), 0.5), 1.0), 1.0);
-}
 
 template <int STRIDE>   // doubles between the LDS slots of one cell; 0: every slot in registers
 struct PointCache {
@@ -259,7 +243,7 @@ struct PointLocal {
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wsometimes-uninitialized"  // den ... tA are set on exactly one of the two paths below
 // VD: the time-varying porosity diffusion coefficient (marl_params.dPhi_variable) - compiled in only where asked for.
-template <int MODE, int STRIDE, bool VD = false, bool WIDE = false>
+template <int MODE, int STRIDE, bool VD = false>
 __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask, const HotConsts& K, const DevConsts* __restrict__ C,
                                             const Tables& T, PointLocal& pl, PointAux& aux, PointCache<STRIDE>& pc, bool& live)
 {
@@ -284,11 +268,10 @@ __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask
         const double v = dO * pc.nib;
         // every expansion variable below is bounded by this sum (NaN compares false -> falls back)
         const double big = __builtin_fma(fabs(d), pc.cPhi, fabs(v));
-        reuse = __builtin_amdgcn_ballot_w64(!(big < (WIDE ? REUSE_WIDE : REUSE_LIMIT))) == 0;
+        reuse = __builtin_amdgcn_ballot_w64(!(big < REUSE_LIMIT)) == 0;
         live = reuse;
         if (reuse) {
             const bool tiny = __builtin_amdgcn_ballot_w64(!(big < REUSE_TINY)) == 0;
-            const bool narrow = !WIDE || __builtin_amdgcn_ballot_w64(!(big < REUSE_LIMIT)) == 0;
             const double invPhi0 = pc.get(PC_INVPHI), invom0 = pc.get(PC_INVOM), invden0 = pc.get(PC_INVDEN), ib0 = pc.get(PC_IB);
             const double e0 = pc.get(PC_E), tC0 = pc.get(PC_TC);
             const double x = d * invPhi0, y = d * invom0, u = dO * ib0;
@@ -298,16 +281,11 @@ __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask
                 ip = invPhi0 * __builtin_fma(-x, 1.0 - x, 1.0);                           // 1/(Phi0 (1+x))
                 w = v * __builtin_fma(u, -0.5, 1.0);                                      // n log1p(u)
                 gy = __builtin_fma(y, 1.0 + y, 1.0);                                      // 1/(1-y)
-            } else if (narrow) {
+            } else {
                 l1p = x * __builtin_fma(x, __builtin_fma(x, 1.0 / 3, -0.5), 1.0);
                 ip = invPhi0 * __builtin_fma(-x, __builtin_fma(-x, 1.0 - x, 1.0), 1.0);
                 w = v * __builtin_fma(u, __builtin_fma(u, 1.0 / 3, -0.5), 1.0);
                 gy = __builtin_fma(y, __builtin_fma(y, 1.0 + y, 1.0), 1.0);
-            } else {   // 6th order
-                l1p = x * series_log1p6(x);
-                ip = invPhi0 * series_geom6(-x);
-                w = v * series_log1p6(u);
-                gy = series_geom6(y);
             }
             const double z = -2.0 * l1p * invden0;                                        // (den - den0)/den0
             const double da = -10.0 * (ip - invPhi0);                                     // change of 10 - 10/Phi
@@ -317,14 +295,10 @@ __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask
                 invden = invden0 * __builtin_fma(-z, 1.0 - z, 1.0);
                 ex = e0 * __builtin_fma(da, __builtin_fma(da, 0.5, 1.0), 1.0);
                 tC = tC0 * __builtin_fma(w, __builtin_fma(w, 0.5, 1.0), 1.0);
-            } else if (narrow) {
+            } else {
                 invden = invden0 * __builtin_fma(-z, __builtin_fma(-z, 1.0 - z, 1.0), 1.0);
                 ex = e0 * __builtin_fma(da, __builtin_fma(da, __builtin_fma(da, 1.0 / 6, 0.5), 1.0), 1.0);
                 tC = tC0 * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.0 / 6, 0.5), 1.0), 1.0);
-            } else {
-                invden = invden0 * series_geom6(-z);
-                ex = e0 * series_exp6(da);
-                tC = tC0 * series_exp6(w);
             }
             // wave-uniform on purpose: a per-lane condition is if-converted, and the Peclet test (with the reciprocal
             // that recovers den) would then run in every evaluation

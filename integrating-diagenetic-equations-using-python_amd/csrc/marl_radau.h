@@ -441,42 +441,45 @@ __device__ void pcr_factor_group(const double* __restrict__ J, int64_t N, int le
         if (act) S.Dinv[0][i * 25 + e] = inv;
         return;
     }
-    const int cur = level & 1, nxt = cur ^ 1;
+    // (selects, not S.x[level & 1]: a runtime index into the argument struct would put the struct into scratch)
+    const bool odd = level & 1;
+    const T *Lc = odd ? S.L[1] : S.L[0], *Dc = odd ? S.D[1] : S.D[0], *Uc = odd ? S.U[1] : S.U[0], *Ic = odd ? S.Dinv[1] : S.Dinv[0];
+    T *Ln = odd ? S.L[0] : S.L[1], *Dn_ = odd ? S.D[0] : S.D[1], *Un = odd ? S.U[0] : S.U[1], *In = odd ? S.Dinv[0] : S.Dinv[1];
     const int64_t s = (int64_t)1 << level;
     const int ee = act ? e : 0;
-    d = S.D[cur][ic * 25 + ee];
+    d = Dc[ic * 25 + ee];
     const T zero = lift(0.0, mu);
     // lower side: alpha = -L D_{i-s}^-1;  D += alpha U_{i-s};  L' = alpha L_{i-s}
     const bool lo = ic - s >= 0;
     T al = zero, ln = zero;
     __syncthreads();
-    if (act && lo) { st.A[e] = S.L[cur][i * 25 + e]; st.B[e] = S.Dinv[cur][(i - s) * 25 + e]; }
+    if (act && lo) { st.A[e] = Lc[i * 25 + e]; st.B[e] = Ic[(i - s) * 25 + e]; }
     __syncthreads();
     if (act && lo) al = lift(-1.0, mu) * mm_elem<T>(st.A, st.B, r, c);
     __syncthreads();
-    if (act && lo) { st.A[e] = al; st.B[e] = S.U[cur][(i - s) * 25 + e]; st.C[e] = S.L[cur][(i - s) * 25 + e]; }
+    if (act && lo) { st.A[e] = al; st.B[e] = Uc[(i - s) * 25 + e]; st.C[e] = Lc[(i - s) * 25 + e]; }
     __syncthreads();
     if (act && lo) { d = d + mm_elem<T>(st.A, st.B, r, c); ln = mm_elem<T>(st.A, st.C, r, c); }
     // upper side: gamma = -U D_{i+s}^-1;  D += gamma L_{i+s};  U' = gamma U_{i+s}
     const bool hi = ic + s < N;
     T ga = zero, un = zero;
     __syncthreads();
-    if (act && hi) { st.A[e] = S.U[cur][i * 25 + e]; st.B[e] = S.Dinv[cur][(i + s) * 25 + e]; }
+    if (act && hi) { st.A[e] = Uc[i * 25 + e]; st.B[e] = Ic[(i + s) * 25 + e]; }
     __syncthreads();
     if (act && hi) ga = lift(-1.0, mu) * mm_elem<T>(st.A, st.B, r, c);
     __syncthreads();
-    if (act && hi) { st.A[e] = ga; st.B[e] = S.L[cur][(i + s) * 25 + e]; st.C[e] = S.U[cur][(i + s) * 25 + e]; }
+    if (act && hi) { st.A[e] = ga; st.B[e] = Lc[(i + s) * 25 + e]; st.C[e] = Uc[(i + s) * 25 + e]; }
     __syncthreads();
     if (act && hi) { d = d + mm_elem<T>(st.A, st.B, r, c); un = mm_elem<T>(st.A, st.C, r, c); }
     if (act) {
         S.alpha[((int64_t)level * N + i) * 25 + e] = al;
         S.gamma[((int64_t)level * N + i) * 25 + e] = ga;
-        S.L[nxt][i * 25 + e] = ln;
-        S.U[nxt][i * 25 + e] = un;
-        S.D[nxt][i * 25 + e] = d;
+        Ln[i * 25 + e] = ln;
+        Un[i * 25 + e] = un;
+        Dn_[i * 25 + e] = d;
     }
     const T inv = gj_inverse_elem<T>(d, e, r, c, act, st);
-    if (act) S.Dinv[nxt][i * 25 + e] = inv;
+    if (act) In[i * 25 + e] = inv;
 }
 
 // blockIdx.y: 0 real system, 1 complex system.  level < 0: initialise from J.
@@ -513,7 +516,7 @@ __device__ __forceinline__ void pcr_solve_row(int64_t N, int64_t kk, int level, 
         }
         bout[kk] = acc;
     } else {   // x_i = D_i^-1 b_i
-        const T* di = S.Dinv[nlevels & 1] + i * 25 + r * NF;
+        const T* di = ((nlevels & 1) ? S.Dinv[1] : S.Dinv[0]) + i * 25 + r * NF;
         T acc = di[0] * bin[i * NF];
 #pragma unroll
         for (int k = 1; k < NF; k++) acc = acc + di[k] * bin[i * NF + k];
