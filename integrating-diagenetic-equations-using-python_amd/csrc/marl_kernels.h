@@ -216,7 +216,12 @@ struct ZBatch {
     int want;
     const int32_t* list;
 };
-__device__ __forceinline__ int64_t z_inst(const ZBatch& B) { return B.list ? (int64_t)B.list[blockIdx.z] : (int64_t)blockIdx.z; }
+// (readfirstlane: the index is the same in every lane, but a load through a struct member is not provably so - without it every
+// shifted pointer becomes a per-lane 64-bit address and the PCR kernels of a single large grid ran 3x slower)
+__device__ __forceinline__ int64_t z_inst(const ZBatch& B)
+{
+    return B.list ? (int64_t)__builtin_amdgcn_readfirstlane(B.list[blockIdx.z]) : (int64_t)blockIdx.z;
+}
 __device__ __forceinline__ bool z_masked_out(const ZBatch& B)
 {
     return B.act && !(*reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(B.act) + z_inst(B) * B.act_stride) & B.want);
