@@ -474,6 +474,33 @@ def main():
                     e["cpu_oracle_nfev_njev_nlu"] = [int(st.nfev), int(st.njev), int(st.nlu)]
                 res[f"N{Nr}"] = e
             extra["implicit_radau_scenarioA_to_Tstar"] = res
+            # a SWEEP with the same solver: 512 scenarios (Phi0 x PhiIni x k3 = k4 grid), N = 200, all advanced together
+            Bs, Ns = 512, 200
+            kk = 8
+            inst = [{"Phi0": 0.5 + 0.2 * ((i % kk) / (kk - 1)), "PhiIni": 0.5 + 0.2 * (((i // kk) % kk) / (kk - 1)),
+                     "k3": 10 ** (-2 + ((i // (kk * kk)) % kk) / (kk - 1))} for i in range(Bs)]
+            for d in inst:
+                d["PhiNR"] = d["PhiIni"]
+                d["k4"] = d["k3"]
+            ps = base | {"N": Ns}
+            y0 = np.stack([np.concatenate([np.full(Ns, (ps | d)[q]) for q in ("CAIni", "CCIni", "cCaIni", "cCO3Ini", "PhiIni")]) for d in inst])
+            eq = LMAHeureuxPorosityDiff.from_scenario(ps, device=local_rank, instances=inst)
+            eq.use_stream(stream.cuda_stream)
+            yd = torch.from_numpy(y0).cuda()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rs = eq.sweep_radau_device(yd.data_ptr(), (0.0, 1.0), 1e-6, 1e-3, 1e-3)
+            sw = {"instances": Bs, "N": Ns, "seconds": time.perf_counter() - t0, "reached_Tstar": int(sum(r.status == 0 for r in rs)),
+                  "nfev_median": float(np.median([r.nfev for r in rs])), "nfev_max": int(max(r.nfev for r in rs))}
+            eq.close()
+            if rank == 0 and not args.no_cpu_baseline:
+                from oracle import oracle as orc
+                sample = list(range(0, Bs, Bs // 16))
+                t0 = time.perf_counter()
+                for b in sample:
+                    orc.radau(orc.params_from_dict(ps | inst[b]), Ns, y0[b], 0.0, 1.0, 1e-6, 1e-3, 1e-3)
+                sw["cpu_oracle_seconds_1_core_extrapolated"] = (time.perf_counter() - t0) / len(sample) * Bs
+            extra["implicit_radau_sweep"] = sw
 
         guarded("BASELINE_configs1_rk4_N65536", x_n65536)
         guarded("rk4_N1048576_no_reuse", x_no_reuse)
