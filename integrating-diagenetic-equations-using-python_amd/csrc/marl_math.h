@@ -64,6 +64,7 @@ struct DevConsts {
 };
 
 constexpr double PECLET_MIN = 1e-2, PECLET_MAX = 1.0 / PECLET_MIN;  // LHeureux_model.py:87-88
+constexpr double FV_SERIES_MAX = 0.5;   // below: power series of coth x - 1/x (fv_sigma)
 
 // Pin a uniform value in scalar registers: the empty asm makes it opaque, so under register pressure
 // the compiler spills it (v_writelane) instead of re-issuing the s_load + s_waitcnt it came from.
@@ -161,6 +162,9 @@ __device__ __forceinline__ double pow_sat(double b, double e, const Tables& T)
 }
 
 // Fiadeiro-Veronis weight sigma(Pe) for |Pe| >= PECLET_MIN; LHeureux_model.py:437-442 (= calculate_sigma :147-160)
+// SERIES: the fused explicit integrators.  The stand-alone RHS (and with it the implicit path, whose Newton / step-size
+// decisions are compared with scipy's run on the reference's RHS decision by decision) keeps the closed form throughout.
+template <bool SERIES>
 __device__ __forceinline__ double fv_sigma(double Pe, double W, const Tables& T)
 {
     const double a = fabs(Pe);
@@ -168,8 +172,28 @@ __device__ __forceinline__ double fv_sigma(double Pe, double W, const Tables& T)
     if (a > PECLET_MAX) {
         s = (W > 0.0) ? 1.0 : ((W < 0.0) ? -1.0 : W);  // np.sign(W) incl. 0 and NaN
     } else if (!(a < PECLET_MIN)) {
-        // cosh/sinh - 1/Pe  ==  1 + 2/(e^(2 Pe) - 1) - 1/Pe ;  |Pe| in [1e-2, 1e2]
-        s = (1.0 + 2.0 * rcp_nr(fast_exp(2.0 * Pe, T) - 1.0)) - rcp_nr(Pe);
+        if (SERIES && a <= FV_SERIES_MAX) {
+            // coth x - 1/x = sum_k B_2k 4^k x^(2k-1) / (2k)!  (ratio of terms -> -x^2/pi^2): eleven terms are exact to
+            // < 1e-16 relative for |x| <= 0.5 - where the closed form below cancels 1/x against coth x and loses
+            // eps/x^2 - at a third of its cost (no exp, no reciprocal).  The one-workgroup sweeps (N = 1024,
+            // |Pe_Phi| ~ 0.1 - 0.2) live here.
+            const double x2 = Pe * Pe;
+            double p = 2.3106432599002624e-11;
+            p = __builtin_fma(p, x2, -2.2805151204592183e-10);
+            p = __builtin_fma(p, x2, 2.2507846516808994e-09);
+            p = __builtin_fma(p, x2, -2.2214608789979678e-08);
+            p = __builtin_fma(p, x2, 2.1925947851873778e-07);
+            p = __builtin_fma(p, x2, -2.1644042808063972e-06);
+            p = __builtin_fma(p, x2, 2.1377799155576935e-05);
+            p = __builtin_fma(p, x2, -1.0 / 4725);
+            p = __builtin_fma(p, x2, 2.0 / 945);
+            p = __builtin_fma(p, x2, -1.0 / 45);
+            p = __builtin_fma(p, x2, 1.0 / 3);
+            s = p * Pe;
+        } else {
+            // cosh/sinh - 1/Pe  ==  1 + 2/(e^(2 Pe) - 1) - 1/Pe ;  |Pe| in (0.5, 1e2]
+            s = (1.0 + 2.0 * rcp_nr(fast_exp(2.0 * Pe, T) - 1.0)) - rcp_nr(Pe);
+        }
     }
     return s;
 }
@@ -425,7 +449,7 @@ __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask
 
 // uc/um/up: values at cell i, i-1, i+1 (ghosts already substituted).  r: the five rates (LHeureux_model.py:498-520).
 // mixed_upwind (wave-uniform): false promises pl.upw in every lane of the wave - up[0], up[1] are then not read.
-template <bool VD = false>
+template <bool VD = false, bool SERIES = true>
 __device__ __forceinline__ void point_rates(const double (&uc)[NF], const double (&um)[NF], const double (&up)[NF],
                                             const HotConsts& K, const Tables& T, const PointLocal& pl, double (&r)[NF], bool mixed_upwind = true)
 {
@@ -466,7 +490,7 @@ __device__ __forceinline__ void point_rates(const double (&uc)[NF], const double
     } else {
         const double W = pl.W, Wd = pl.Wd;
         const double pe_Phi = VD ? K.pe_Phi * (K.dPhi * rcp_nr(dPhi_cell())) : K.pe_Phi;   // delta_x / (2 dPhi)
-        const double s_c = fv_sigma(Wd * K.pe_cCa, W, T), s_o = fv_sigma(Wd * K.pe_cCO3, W, T), s_p = fv_sigma(W * pe_Phi, W, T);
+        const double s_c = fv_sigma<SERIES>(Wd * K.pe_cCa, W, T), s_o = fv_sigma<SERIES>(Wd * K.pe_cCO3, W, T), s_p = fv_sigma<SERIES>(W * pe_Phi, W, T);
         cg = ((1.0 - s_c) * c_f + (1.0 + s_c) * c_b) * K.hdx;
         og = ((1.0 - s_o) * o_f + (1.0 + s_o) * o_b) * K.hdx;
         pg = ((1.0 - s_p) * p_f + (1.0 + s_p) * p_b) * K.hdx;
@@ -493,7 +517,7 @@ __device__ __forceinline__ void rhs_point(const double (&uc)[NF], const double (
 {
     PointLocal pl;
     point_local<MODE, STRIDE, VD>(uc, in_mask, K, C, T, pl, aux, pc, live);
-    point_rates<VD>(uc, um, up, K, T, pl, r);
+    point_rates<VD, false>(uc, um, up, K, T, pl, r);
 }
 
 

@@ -93,3 +93,11 @@ def test_reciprocal_and_sigma(eq):
         ref = np.where(a < 1e-2, 0.0, np.where(a > 100, np.sign(-4.28), np.cosh(pe) / np.sinh(pe) - 1 / pe))
     print("sigma: max abs error:", np.max(np.abs(got - ref)))
     assert np.max(np.abs(got - ref)) <= 2e-12     # cancellation near |Pe| = 1e-2 on both sides (coth ~ 100)
+    # the fused integrators' variant (op 5): power series for |Pe| <= 0.5, the closed form beyond; checked against the closed form
+    # in extended precision (whose own cancellation error is eps_80bit / Pe^2 <= 1e-15 relative)
+    got5 = probe(eq, 5, pe, -4.28)
+    assert np.array_equal(got5[a > 0.5], got[a > 0.5]) and np.all(got5[a < 1e-2] == 0.0)
+    m = (a >= 1e-2) & (a <= 0.5)
+    xl = pe[m].astype(np.longdouble)
+    refl = (np.cosh(xl) / np.sinh(xl) - 1 / xl).astype(np.float64)
+    assert np.max(np.abs(got5[m] - refl) / np.abs(refl)) <= (1e-14 if np.finfo(np.longdouble).eps < 1e-18 else 1e-11)
