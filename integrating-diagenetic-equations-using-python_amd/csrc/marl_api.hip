@@ -38,6 +38,13 @@ struct marl_ctx {
     size_t buf_cap[4] = {0, 0, 0, 0};
     double* part = nullptr;
     size_t part_cap = 0;
+    // streamed RK4 (rk4_stream_kernel): work queue {next item, abort flag} + one published-level counter per tile
+    unsigned* sq = nullptr;
+    size_t sq_cap = 0;
+    unsigned* sq_sticky = nullptr; // device: raised by a streamed run that gave up waiting; cleared by the host only
+    unsigned* sq_host = nullptr;   // pinned: copy of sq_sticky
+    bool sq_pending = false;       // streamed runs since sq_sticky was last looked at
+    int cus = 0;
     double* rec = nullptr;  // [batch][NQ]
     Rk45Ctrl* dctrl = nullptr;
     Rk45Ctrl* hctrl = nullptr;  // pinned
@@ -59,6 +66,7 @@ struct marl_ctx {
     double* rd_host = nullptr;  // pinned: [0] norm^2, [1] flags (as int32), [2..] spare
     // options
     int64_t rk4_variant = -1, rk45_variant = -1, sweep_variant = -1, host_layout = LAYOUT_TILED, poll = 64;
+    int64_t rk4_stream = 1;     // the fixed-step loop of one grid as ONE dataflow launch (rk4_stream_kernel): 0 never, 1 large grids, 2 always
     int64_t radau_solver = 0;   // 0: block parallel cyclic reduction (parallel over depth); 1: sequential block Thomas
     std::string err;
 };
@@ -238,6 +246,9 @@ void marl_ctx_destroy(marl_ctx* ctx)
     for (int i = 0; i < 4; i++)
         if (ctx->buf[i]) (void)hipFree(ctx->buf[i]);
     if (ctx->part) (void)hipFree(ctx->part);
+    if (ctx->sq) (void)hipFree(ctx->sq);
+    if (ctx->sq_sticky) (void)hipFree(ctx->sq_sticky);
+    if (ctx->sq_host) (void)hipHostFree(ctx->sq_host);
     if (ctx->rec) (void)hipFree(ctx->rec);
     if (ctx->dctrl) (void)hipFree(ctx->dctrl);
     if (ctx->ddt) (void)hipFree(ctx->ddt);
@@ -263,11 +274,26 @@ int marl_set_stream(marl_ctx* ctx, void* hip_stream)
     return 0;
 }
 
+// A streamed RK4 run (rk4_stream_kernel) that gave up waiting raises a sticky device flag; the device entry points stay
+// asynchronous, so the flag is looked at where the caller synchronises anyway: marl_synchronize and the host-pointer entry points.
+static int stream_check(marl_ctx* ctx)
+{
+    if (!ctx->sq_pending) return 0;
+    HIP_OK(ctx, hipMemcpyAsync(ctx->sq_host, ctx->sq_sticky, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->sq_pending = false;
+    if (*ctx->sq_host) {
+        HIP_OK(ctx, hipMemsetAsync(ctx->sq_sticky, 0, sizeof(unsigned), ctx->stream));
+        return fail(ctx, -2, "rk4: the streamed time loop gave up waiting for a neighbouring tile (rk4_stream_kernel); the state is invalid");
+    }
+    return 0;
+}
+
 int marl_synchronize(marl_ctx* ctx)
 {
     if (!ctx) return -1;
     HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
+    return stream_check(ctx);
 }
 
 int marl_set_option(marl_ctx* ctx, const char* name, int64_t value)
@@ -280,6 +306,7 @@ int marl_set_option(marl_ctx* ctx, const char* name, int64_t value)
     else if (n == "host_layout") ctx->host_layout = value ? LAYOUT_TILED : LAYOUT_FIELD_MAJOR;
     else if (n == "poll_interval") ctx->poll = value > 0 ? value : 1;
     else if (n == "radau_solver") ctx->radau_solver = value ? 1 : 0;
+    else if (n == "rk4_stream") ctx->rk4_stream = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "no_reuse") {
         // every evaluation of the fused kernels takes its full path (what a rough state does wave by wave): re-upload the constants
         for (auto& c : ctx->hconsts) c.hot.no_reuse = value ? 1 : 0;
@@ -424,6 +451,66 @@ static int default_rk4_variant(const marl_ctx* ctx)
     return n <= 98304 ? 4 : (n <= 262144 ? 3 : 2);
 }
 
+// One dataflow launch for `levels` x `per` steps (rk4_stream_kernel): bufA -> ... -> (levels odd ? bufB : bufA)
+template <int NSTEPS, bool VD = false>
+static void launch_stream_t(marl_ctx* ctx, double* a, double* b, int layout, double dt, unsigned levels, unsigned tiles, unsigned blocks)
+{
+    if (layout == LAYOUT_TILED)
+        hipLaunchKernelGGL((rk4_stream_kernel<256, LAYOUT_TILED, NSTEPS, VD>), dim3(blocks), dim3(256), 0, ctx->stream, a, b, ctx->dconsts, ctx->slab, dt,
+                           levels, tiles, ctx->sq, ctx->sq + 2, ctx->sq_sticky);
+    else
+        hipLaunchKernelGGL((rk4_stream_kernel<256, LAYOUT_FIELD_MAJOR, NSTEPS, VD>), dim3(blocks), dim3(256), 0, ctx->stream, a, b, ctx->dconsts, ctx->slab,
+                           dt, levels, tiles, ctx->sq, ctx->sq + 2, ctx->sq_sticky);
+}
+
+static int rk4_stream(marl_ctx* ctx, double* a, double* b, int layout, double dt, int per, int64_t levels)
+{
+    const int64_t n = ctx->slab.out_hi - ctx->slab.out_lo, V = 256 - 8 * per, tiles = (n + V - 1) / V;
+    if (!ctx->cus) {
+        hipDeviceProp_t prop;
+        HIP_OK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        ctx->cus = prop.multiProcessorCount;
+    }
+    if (!ctx->sq_host) HIP_OK(ctx, hipHostMalloc((void**)&ctx->sq_host, sizeof(unsigned), hipHostMallocDefault));
+    if (!ctx->sq_sticky) {
+        HIP_OK(ctx, hipMalloc((void**)&ctx->sq_sticky, sizeof(unsigned)));
+        HIP_OK(ctx, hipMemsetAsync(ctx->sq_sticky, 0, sizeof(unsigned), ctx->stream));
+    }
+    if (ctx->sq_cap < (size_t)tiles + 2) {
+        if (ctx->sq) HIP_OK(ctx, hipFree(ctx->sq));
+        ctx->sq = nullptr;
+        ctx->sq_cap = 0;
+        HIP_OK(ctx, hipMalloc((void**)&ctx->sq, ((size_t)tiles + 2) * sizeof(unsigned)));
+        ctx->sq_cap = (size_t)tiles + 2;
+    }
+    while (levels > 0) {
+        // (the item counter is 32 bits wide; an even number of levels per launch keeps the ping-pong orientation)
+        const int64_t cap = ((int64_t)0x7fffffff / tiles) & ~(int64_t)1;
+        const int64_t lv = std::min<int64_t>(levels, std::max<int64_t>(cap, 2));
+        HIP_OK(ctx, hipMemsetAsync(ctx->sq, 0, ((size_t)tiles + 2) * sizeof(unsigned), ctx->stream));
+        const unsigned blocks = (unsigned)std::min<int64_t>(lv * tiles, 4 * (int64_t)ctx->cus);   // 4 workgroups of 256 per CU are resident
+        switch (per) {
+            case 1: if (ctx->var_dphi) launch_stream_t<1, true>(ctx, a, b, layout, dt, (unsigned)lv, (unsigned)tiles, blocks);
+                    else launch_stream_t<1>(ctx, a, b, layout, dt, (unsigned)lv, (unsigned)tiles, blocks);
+                    break;
+            case 2: launch_stream_t<2>(ctx, a, b, layout, dt, (unsigned)lv, (unsigned)tiles, blocks); break;
+            case 4: if (ctx->var_dphi) launch_stream_t<4, true>(ctx, a, b, layout, dt, (unsigned)lv, (unsigned)tiles, blocks);
+                    else launch_stream_t<4>(ctx, a, b, layout, dt, (unsigned)lv, (unsigned)tiles, blocks);
+                    break;
+            case 8: launch_stream_t<8>(ctx, a, b, layout, dt, (unsigned)lv, (unsigned)tiles, blocks); break;
+            case 16: launch_stream_t<16>(ctx, a, b, layout, dt, (unsigned)lv, (unsigned)tiles, blocks); break;
+            default: return fail(ctx, -1, "rk4 stream: %d steps per level not instantiated", per);
+        }
+        LAUNCH_OK(ctx);
+        ctx->sq_pending = true;
+        levels -= lv;
+        if (levels > 0 && (lv & 1)) std::swap(a, b);
+    }
+    return 0;
+}
+
+constexpr int64_t kStreamMinCells = 196608;
+
 // y (device, `layout`) advanced in place; `tmp` is a second buffer of the same size
 static int rk4_run(marl_ctx* ctx, double* y, double* tmp, int layout, double dt, int64_t nsteps)
 {
@@ -432,6 +519,16 @@ static int rk4_run(marl_ctx* ctx, double* y, double* tmp, int layout, double dt,
     double* a = y;
     double* b = tmp;
     int64_t left = nsteps;
+    // One dataflow launch instead of one launch per level where it pays (tools/lab record in profiles/r02_lab_rk4_stream.log):
+    // from ~200 000 cells (below, the tiles do not fill the resident workgroups and the state is served from the L2s anyway).
+    const bool stream = ctx->rk4_stream == 2 ? left >= per
+                                             : (ctx->rk4_stream == 1 && ctx->slab.out_hi - ctx->slab.out_lo >= kStreamMinCells && left >= 2 * per);
+    if (stream && ctx->halo == 0) {
+        const int64_t levels = left / per;
+        if (int rc = rk4_stream(ctx, a, b, layout, dt, per, levels)) return rc;
+        if (levels & 1) std::swap(a, b);
+        left -= levels * per;
+    }
     while (left >= per) {
         if (int rc = launch_rk4(ctx, v, per, a, b, layout, dt)) return rc;
         std::swap(a, b);
@@ -843,7 +940,7 @@ int marl_integrate_rk4(marl_ctx* ctx, double* y, double dt, int64_t nsteps)
     }
     HIP_OK(ctx, hipMemcpyAsync(y, ctx->buf[2], n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
+    return stream_check(ctx);
 }
 
 int marl_sweep_rk45_dev(marl_ctx* ctx, double* y_dev, double t0, double t1, double first_step, double rtol, double atol,

@@ -420,31 +420,13 @@ __device__ __forceinline__ void load_cells(const double* __restrict__ y, int64_t
 #ifdef MARL_LAB_CLOCK  // kernel-lab diagnostic build only: in-kernel shader clock (s_memtime) vs 100 MHz s_memrealtime
 __device__ unsigned long long marl_lab_clock[3 * 16384];
 #endif
-// One cell per thread: 4 waves per SIMD (<= 128 VGPRs; 4 workgroups of 256 share the CU's 160 KB of LDS).
-// Variants with more cells per thread keep the compiler's own choice.
-template <int BLK, int CPT, int LAYOUT, int NSTEPS, bool VD = false>
-__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(CPT == 1 ? 4 : 1, 8))) rk4_fused_kernel(const double* __restrict__ yin, double* __restrict__ yout,
-                                                        const DevConsts* __restrict__ consts, Slab S, double dt)
+// NSTEPS classical RK4 steps on the thread's cells (every evaluation invalidates one more cell per window edge).
+template <int NSTEPS, class SB, int CPT>
+__device__ __forceinline__ void rk4_advance(SB& sb, double (&y)[CPT][NF], double dt)
 {
-#ifdef MARL_LAB_CLOCK
-    const unsigned long long lab_t0 = __builtin_amdgcn_s_memtime(), lab_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    constexpr int H = 4 * NSTEPS;
-    constexpr int WIN = BLK * CPT;
-    constexpr int V = WIN - 2 * H;
-    static_assert(V > 0, "window too small for the fused halo");
-    using SB = StencilBlock<BLK, CPT, true, VD>;
-    __shared__ double lds[SB::LDS_DOUBLES];
-    const DevConsts& C = consts[0];
-
-    const int64_t w0 = S.out_lo + (int64_t)blockIdx.x * V - H;  // window start, local index
-    const int64_t l0 = w0 + (int64_t)threadIdx.x * CPT;
-    double y[CPT][NF], ys[CPT][NF], k[CPT][NF], acc[CPT][NF];
+    double ys[CPT][NF], k[CPT][NF], acc[CPT][NF];
     PointAux aux[CPT];
-    load_cells<CPT, LAYOUT>(yin, l0, S, C, y);              // in flight while the tables are staged
-    SB sb(lds, l0 + S.goff, consts);   // (table copy + barrier inside)
     const double h2 = 0.5 * dt, h6 = dt / 6.0;
-
 #pragma unroll 1
     for (int step = 0; step < NSTEPS; step++) {
         sb.template eval<TR_AUTO>(y, k, aux);   // the centre of the expansions survives from step to step
@@ -468,6 +450,31 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(CPT ==
 #pragma unroll
             for (int f = 0; f < NF; f++) y[c][f] = y[c][f] + h6 * (acc[c][f] + k[c][f]);
     }
+}
+
+// One cell per thread: 4 waves per SIMD (<= 128 VGPRs; 4 workgroups of 256 share the CU's 160 KB of LDS).
+// Variants with more cells per thread keep the compiler's own choice.
+template <int BLK, int CPT, int LAYOUT, int NSTEPS, bool VD = false>
+__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(CPT == 1 ? 4 : 1, 8))) rk4_fused_kernel(const double* __restrict__ yin, double* __restrict__ yout,
+                                                        const DevConsts* __restrict__ consts, Slab S, double dt)
+{
+#ifdef MARL_LAB_CLOCK
+    const unsigned long long lab_t0 = __builtin_amdgcn_s_memtime(), lab_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    constexpr int H = 4 * NSTEPS;
+    constexpr int WIN = BLK * CPT;
+    constexpr int V = WIN - 2 * H;
+    static_assert(V > 0, "window too small for the fused halo");
+    using SB = StencilBlock<BLK, CPT, true, VD>;
+    __shared__ double lds[SB::LDS_DOUBLES];
+    const DevConsts& C = consts[0];
+
+    const int64_t w0 = S.out_lo + (int64_t)blockIdx.x * V - H;  // window start, local index
+    const int64_t l0 = w0 + (int64_t)threadIdx.x * CPT;
+    double y[CPT][NF];
+    load_cells<CPT, LAYOUT>(yin, l0, S, C, y);              // in flight while the tables are staged
+    SB sb(lds, l0 + S.goff, consts);   // (table copy + barrier inside)
+    rk4_advance<NSTEPS>(sb, y, dt);
 
 #pragma unroll
     for (int c = 0; c < CPT; c++) {
@@ -485,6 +492,105 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(CPT ==
         marl_lab_clock[3 * blockIdx.x + 2] = lab_r0;
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// The whole fixed-step loop of ONE large grid in ONE launch: a dataflow schedule over (level, tile) work items.
+//
+// A launch of rk4_fused_kernel is a global barrier: with waves that run ~20 us and only ~4.6 "rounds" of them per launch
+// (N = 2^20: 18 728 waves on 4096 slots), the partially filled last round and the ramp-up leave the SIMDs with 3.3 instead
+// of 4 resident waves on average (SQ counters) - and tile t of the next level only needs tiles t-1, t, t+1 of
+// this one.  So: `levels` x `tiles` work items (a tile = the V cells one window writes, a level = NSTEPS steps), handed out in
+// level-major order by an atomic counter to a grid of resident workgroups; an item waits until the three tiles it reads have
+// published the previous level, computes exactly what the workgroup of the per-level launch computes (bit-identical results),
+// and publishes its tile.  Ping-pong between two buffers is safe: neighbours can never be more than one level apart.
+//   * Progress: an item only waits for items with smaller numbers, which were handed out earlier to workgroups that are
+//     running - the smallest unfinished item never waits.  Every wait is bounded (STREAM_SPIN_LIMIT polls, ~1 s): on expiry,
+//     or when any workgroup has raised queue[1], the workgroup raises queue[1] and leaves; the host reports the error.
+//   * Coherence: tiles cross XCDs (one L2 each).  A release fence at agent scope writes back the XCD's whole L2 (measured 4x
+//     slower, profiles/r02_lab_rk45_fused_control.log); instead the state itself moves with agent-scope (sc1: write-through /
+//     L2-bypassing) stores and loads, and a tile is published - done[tile] = level + 1, also sc1 - only after every thread's
+//     stores have been acknowledged (s_waitcnt vmcnt(0) + barrier).  The path is bound by the fp64 VALU, not by memory:
+//     80 MB per level through the Infinity Fabric instead of the L2s costs nothing measurable.
+// queue[0]: next item; queue[1]: abort flag; done[tiles]: levels published - all zero at launch.  sticky: raised with queue[1]
+// and never cleared by the device: the host looks at it at its next synchronisation point (marl_synchronize).
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned STREAM_SPIN_LIMIT = 1u << 19;
+
+template <int BLK, int LAYOUT, int NSTEPS, bool VD = false>
+__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8)))
+rk4_stream_kernel(double* bufA, double* bufB, const DevConsts* __restrict__ consts, Slab S, double dt, unsigned levels, unsigned tiles,
+                  unsigned* queue, unsigned* done, unsigned* sticky)
+{
+    constexpr int CPT = 1;
+    constexpr int H = 4 * NSTEPS;
+    constexpr int V = BLK - 2 * H;
+    using SB = StencilBlock<BLK, CPT, true, VD>;
+    __shared__ double lds[SB::LDS_DOUBLES];
+    __shared__ unsigned s_item, s_abort;
+    const DevConsts& C = consts[0];
+    SB sb(lds, 0, consts);   // tables once per workgroup (barrier inside)
+    const unsigned total = levels * tiles;   // (host: < 2^31)
+
+    while (true) {
+        // (barrier 1: every wave has left the previous item - s_item / s_abort may be rewritten.  It also separates the
+        // thread-0 block below from the one at the end of the loop body: without it the two are fused across the back-edge
+        // into a private loop of lane 0, whose wave then arrives at the barriers twice per item - seen with NSTEPS = 1: hang.
+        // Taking the next item at the END of the body instead puts the LDS write of s_item into the loop latch, and the
+        // compiler then emits the barrier at the loop header without the s_waitcnt lgkmcnt(0) in front of it: waves read the
+        // previous s_item - seen as partly stale tiles.  tools/lab_src, profiles/r02_lab_rk4_stream.log.)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_item = __hip_atomic_fetch_add(&queue[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_abort = 0;
+        }
+        __syncthreads();
+        const unsigned item = s_item;
+        if (item >= total) break;
+        const unsigned level = item / tiles, tile = item - level * tiles;
+        if (level > 0) {
+            if (threadIdx.x < 3) {
+                const int64_t t = (int64_t)tile - 1 + threadIdx.x;
+                if (t >= 0 && t < (int64_t)tiles) {
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(&done[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < level) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (++spins > STREAM_SPIN_LIMIT ||
+                            ((spins & 255u) == 0 && __hip_atomic_load(&queue[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                            __hip_atomic_store(&queue[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            s_abort = 1;
+                            break;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (s_abort) break;
+        }
+        const double* src = (level & 1u) ? bufB : bufA;
+        double* dst = (level & 1u) ? bufA : bufB;
+        const int64_t l = S.out_lo + (int64_t)tile * V - H + threadIdx.x;
+        const bool in = l >= 0 && l < S.n_buf;
+        double y[CPT][NF];
+#pragma unroll
+        for (int f = 0; f < NF; f++)
+            y[0][f] = in ? __hip_atomic_load(src + at<LAYOUT>(f, l, S.ld), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : C.bc[f];
+        sb.set_window(l + S.goff);
+        sb.reuse_live[0] = false;
+        rk4_advance<NSTEPS>(sb, y, dt);
+        if ((int)threadIdx.x >= H && (int)threadIdx.x < BLK - H && l >= S.out_lo && l < S.out_hi) {
+#pragma unroll
+            for (int f = 0; f < NF; f++) __hip_atomic_store(dst + at<LAYOUT>(f, l, S.ld), y[0][f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __builtin_amdgcn_s_waitcnt(0);   // this thread's stores have been acknowledged (vmcnt = expcnt = lgkmcnt = 0)
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __syncthreads();                 // ... and everybody else's (and everybody has read s_item, s_abort)
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(&done[tile], level + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

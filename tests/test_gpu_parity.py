@@ -165,6 +165,42 @@ def test_rk4_default_kernel_at_config2_size(torch_cuda, oracle, N, layout):
     eq.close()
 
 
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("N,variant,nsteps", [(5003, 2, 4 * 7 + 3), (5003, 3, 8 * 3 + 1), (5003, 0, 9), (5003, 1, 2 * 6 + 1), (700, 2, 4 * 5),
+                                              (65536, -1, 16 * 3 + 5), (1 << 20, -1, 4 * 10 + 2), (300001, -1, 4 * 9), (98304, -1, 16)])
+def test_rk4_streamed_loop_is_bit_identical_to_per_level_launches(torch_cuda, N, variant, nsteps, layout):
+    """The default fixed-step path of one large grid is ONE dataflow launch over (level, tile) work items
+    (rk4_stream_kernel: tiles wait for their three producers of the previous level instead of for a launch boundary).  Every
+    item computes what the workgroup of the per-level launch computes, so the result must be bit-identical to the launch-per-
+    level path (option rk4_stream = 0) - for few tiles (3 at N = 700), many (4682 at N = 2^20), step counts that leave a
+    remainder chain, several fused depths and both layouts (rk4_stream = 2 forces the streamed path below the size from which it
+    is the default); marl_synchronize reports a streamed run that gave up waiting."""
+    torch = torch_cuda
+    p = scenario("default", N)
+    eq = make_model(p)
+    eq.use_stream(torch.cuda.current_stream().cuda_stream)
+    if variant >= 0:
+        eq.set_option("rk4_variant", variant)
+    y = synthetic_state(p, N, amplitude=0.02)
+    dt = 0.25 * (eq.Depths.length / N) ** 2
+    out = []
+    for stream in (0, 2, 2, 2, 2, 1):   # per-level launches, four forced streamed runs (a race would not show every time), the default
+        eq.set_option("rk4_stream", stream)
+        yd = torch.from_numpy(y).cuda()
+        buf = torch.zeros(eq.state_doubles(layout), dtype=torch.float64, device="cuda")
+        eq.convert_layout_device(yd.data_ptr(), buf.data_ptr(), 0, layout)
+        eq.integrate_rk4_device(buf.data_ptr(), dt, nsteps, layout)
+        eq.synchronize()
+        got = torch.empty_like(yd)
+        eq.convert_layout_device(buf.data_ptr(), got.data_ptr(), layout, 0)
+        eq.synchronize()
+        out.append(got.cpu().numpy())
+    assert np.all(np.isfinite(out[0]))
+    for o in out[1:]:
+        assert np.array_equal(o, out[0])
+    eq.close()
+
+
 @pytest.mark.parametrize("name,N", [("default", 200), ("A", 200), ("matlab", 1024), ("stiffphi", 64), ("A", 3000)])
 def test_rk4_host_entry_against_oracle(oracle, name, N):
     """marl_integrate_rk4 (host pointers): small grids take the one-workgroup on-chip path, larger ones the fused path."""
