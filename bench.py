@@ -196,7 +196,9 @@ def main():
         dt = 0.25 * (eq.Depths.length / N) ** 2
         # untimed settle phase (~60 ms of the same kernel): the chip's clocks ramp for tens of ms after idle, and a short
         # --steps run would otherwise measure the ramp; then the W warm-up steps, then the blocks of K timed steps
-        eq.integrate_rk4_device(buf.data_ptr(), dt, 2000, layout)
+        # (as long as the timed call when that is longer: the streamed path is ONE launch per call, and a profile of this
+        # command should see launches of one length)
+        eq.integrate_rk4_device(buf.data_ptr(), dt, max(2000, steps), layout)
         wall, ev_ms, reps = timed(lambda: eq.integrate_rk4_device(buf.data_ptr(), dt, warmup, layout),
                                   lambda: eq.integrate_rk4_device(buf.data_ptr(), dt, steps, layout))
         assert bool(torch.isfinite(buf).all()), "state went non-finite"
@@ -286,7 +288,7 @@ def main():
     # ---- headline -------------------------------------------------------------------------------------------
     single = args.workload in ("rk4_single", "rk45_single", "dd_rk45")
     N = args.n or ((1 << 22) if args.workload == "dd_rk45" else (1 << 20) if single else 1024)
-    defaults = {"rk4_single": (4000, 200), "rk45_single": (2000, 20), "sweep_rk45": (2000, 20), "sweep_rk4": (2000, 20), "dd_rk45": (500, 16)}
+    defaults = {"rk4_single": (4000, 4000), "rk45_single": (2000, 20), "sweep_rk45": (2000, 20), "sweep_rk4": (2000, 20), "dd_rk45": (500, 16)}
     steps = args.steps if args.steps is not None else defaults[args.workload][0]
     warmup = args.warmup if args.warmup is not None else defaults[args.workload][1]
     extra = {}
@@ -301,7 +303,13 @@ def main():
         units = float(N) * steps
         workload = (f"rk4_fused_single_grid N={N} fp64 (north_star target size 2^20; BASELINE configs[1] is the same kernel at "
                     f"N=65536, reported under extra), dt=0.25dx^2" + (", transcendental reuse disabled" if args.no_reuse else ""))
-        kernel, parallelism, scaling = "rk4_fused_kernel", f"{world} rank(s), each integrating its own grid; no collective in the data path", "weak"
+        # marl_api.hip rk4_run: grids of >= 196 608 cells run the whole call as ONE dataflow launch (rk4_stream_kernel) when it
+        # spans at least two fused levels (4 steps each above 262 144 cells, 8 below); the default warm-up equals the timed
+        # call, so that every launch of the kernel in a profile of this command has the same length
+        per = 16 if N <= 98304 else (8 if N <= 262144 else 4)
+        streamed = args.variant < 0 and N >= 196608 and steps >= 2 * per
+        kernel = "rk4_stream_kernel" if streamed else "rk4_fused_kernel"
+        parallelism, scaling = f"{world} rank(s), each integrating its own grid; no collective in the data path", "weak"
     elif args.workload in ("sweep_rk45", "sweep_rk4"):
         wall, ev_ms, reps, info = run_sweep(N, args.batch, steps, warmup, args.workload == "sweep_rk45", args.variant)
         units = float(N) * args.batch * steps
@@ -379,15 +387,18 @@ def main():
                 pmc = (tag, json.load(open(f)))
                 break
         if pmc and args.workload == "rk4_single" and N == (1 << 20) and args.variant < 0:
-            k = next((v for n, v in pmc[1]["kernels"].items() if "rk4_fused_kernel<256, 1, 1, 4" in n), None)
+            want = "rk4_stream_kernel<256, 1, 4" if kernel == "rk4_stream_kernel" else "rk4_fused_kernel<256, 1, 1, 4"
+            k = next((v for n, v in pmc[1]["kernels"].items() if want in n), None)
             if k:
-                launches = steps / 4.0
-                roof["traffic"] = k["hbm_bytes_per_launch"]
-                roof["hbm_measured_gbs"] = k["hbm_bytes_per_launch"] * launches / (ev_ms * 1e-3) / 1e9
+                # one launch of this run = `steps` steps (streamed) or 4 steps (per-level launches); the PMC figure is per step
+                per_step = k["hbm_bytes_per_launch"] / k.get("steps_per_launch", 4)
+                roof["traffic"] = per_step * (steps if kernel == "rk4_stream_kernel" else 4)
+                roof["hbm_measured_gbs"] = per_step * steps / (ev_ms * 1e-3) / 1e9
                 roof["hbm_measured_frac_of_peak"] = roof["hbm_measured_gbs"] / HBM_PEAK_GBS
-                roof["traffic_note"] = ("HBM bytes per launch (4 RK4 steps) from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                roof["traffic_note"] = (f"HBM bytes per launch ({steps if kernel == 'rk4_stream_kernel' else 4} RK4 steps) from rocprofv3 --pmc FETCH_SIZE / "
+                                        f"WRITE_SIZE, separate passes of launches of {k.get('steps_per_launch', 4)} steps scaled by the step count, "
                                         f"FETCH_SIZE doubled per the gfx950 calibration (profiles/{pmc[0]}_pmc_hbm_traffic.json, collected with "
-                                        f"tools/profile_round.sh, not in this run); algorithmic bytes per launch = {k['algorithmic_bytes_per_launch']}")
+                                        f"tools/profile_round.sh, not in this run); algorithmic bytes per step = {80 * N}")
         line = {
             "metric": "grid-point-steps/sec (5 fields, fp64)", "value": value, "unit": "grid-point-steps/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * wall / steps, "reps": reps,

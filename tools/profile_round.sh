@@ -34,10 +34,10 @@ pmc() {  # pmc <tag> <counters...> -- <bench args...>
   shift
   rocprofv3 --pmc "${ctr[@]}" -d "$out/pmc_$tag" --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras "$@" > "$out/pmc_$tag.log" 2>&1
 }
-pmc default_FETCH_SIZE FETCH_SIZE -- --steps 400
-pmc default_WRITE_SIZE WRITE_SIZE -- --steps 400
-pmc default_SQ1 $SQ1 -- --steps 400
-pmc default_SQ2 $SQ2 -- --steps 400
+pmc default_FETCH_SIZE FETCH_SIZE -- --steps 400 --warmup 400
+pmc default_WRITE_SIZE WRITE_SIZE -- --steps 400 --warmup 400
+pmc default_SQ1 $SQ1 -- --steps 400 --warmup 400
+pmc default_SQ2 $SQ2 -- --steps 400 --warmup 400
 pmc rk45_single_FETCH_SIZE FETCH_SIZE -- --workload rk45_single --steps 200
 pmc rk45_single_WRITE_SIZE WRITE_SIZE -- --workload rk45_single --steps 200
 pmc rk45_single_SQ1 $SQ1 -- --workload rk45_single --steps 200

@@ -38,7 +38,10 @@ def counter_table(sub):
 # ---- HBM traffic of the dominant kernels -----------------------------------------------------------------------
 hbm = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (one counter per pass) -- python3 bench.py --no-cpu-baseline --no-extras ... "
                   "(tools/profile_round.sh)", "units": __doc__.split("\n\n")[3].replace("\n", " "), "kernels": {}}
-for wl, pick, alg in (("default", "rk4_fused_kernel<256, 1, 1, 4", 80 * N * 4), ("rk45_single", "rk45_attempt_kernel<256, 1, 1", 160 * N)):
+# (the streamed RK4 kernel: one launch per bench call - bench.py's settle call of 2000 steps, then calls of 400 steps:
+#  tools/profile_round.sh passes --steps 400 --warmup 400 - so the counters are summed over the dispatches and divided by the steps)
+for wl, pick, alg, spl in (("default", "rk4_stream_kernel<256, 1, 4", 80 * N * 400, 400), ("default", "rk4_fused_kernel<256, 1, 1, 4", 80 * N * 4, 4),
+                           ("rk45_single", "rk45_attempt_kernel<256, 1, 1", 160 * N, 1)):
     fe, wr = counter_table(f"pmc_{wl}_FETCH_SIZE"), counter_table(f"pmc_{wl}_WRITE_SIZE")
     cal = None
     for k, v in fe.items():
@@ -48,11 +51,15 @@ for wl, pick, alg in (("default", "rk4_fused_kernel<256, 1, 1, 4", 80 * N * 4), 
         if pick not in k:
             continue
         f, w = fe[k]["FETCH_SIZE"], wr[k]["WRITE_SIZE"]
-        e = {"workload": wl, "FETCH_SIZE_KiB": f[0] / f[1], "WRITE_SIZE_KiB": w[0] / w[1], "dispatches": f[1], "fetch_calibration_factor": cal}
+        if "rk4_stream" in pick:   # per launch of `spl` steps = total / total steps x spl
+            f = [f[0] * spl / (2000 + spl * (f[1] - 1)), 1, 0]
+            w = [w[0] * spl / (2000 + spl * (w[1] - 1)), 1, 0]
+        e = {"workload": wl, "FETCH_SIZE_KiB": f[0] / f[1], "WRITE_SIZE_KiB": w[0] / w[1], "dispatches": fe[k]["FETCH_SIZE"][1], "fetch_calibration_factor": cal}
         e["hbm_read_bytes_per_launch"] = e["FETCH_SIZE_KiB"] * 1024 * (cal or 2.0)
         e["hbm_write_bytes_per_launch"] = e["WRITE_SIZE_KiB"] * 1024
         e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
         e["algorithmic_bytes_per_launch"] = alg
+        e["steps_per_launch"] = spl
         hbm["kernels"][k.replace("void ", "")] = e
 json.dump(hbm, open(os.path.join(dst, f"{tag}_pmc_hbm_traffic.json"), "w"), indent=1)
 
@@ -68,7 +75,7 @@ for wl in ("default", "n65536", "rk45_single", "sweep_rk45", "sweep_rk4"):
                 acc[k]["dispatches"] = n
     out = {}
     for k, m in acc.items():
-        if "marl::" not in k or m.get("dispatches", 0) < 2 or not any(x in k for x in ("rk4_fused", "rk45_attempt", "sweep_kernel", "control", "reduce_chunks")):
+        if "marl::" not in k or m.get("dispatches", 0) < 2 or not any(x in k for x in ("rk4_fused", "rk4_stream", "rk45_attempt", "sweep_kernel", "control", "reduce_chunks")):
             continue
         w = m.get("SQ_WAVES", 0)
         if w and "SQ_INSTS_VALU" in m:
