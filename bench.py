@@ -201,6 +201,7 @@ def main():
         eq.integrate_rk4_device(buf.data_ptr(), dt, max(2000, steps), layout)
         wall, ev_ms, reps = timed(lambda: eq.integrate_rk4_device(buf.data_ptr(), dt, warmup, layout),
                                   lambda: eq.integrate_rk4_device(buf.data_ptr(), dt, steps, layout))
+        eq.synchronize()   # (outside the timed region: surfaces a streamed run that gave up waiting - marl_synchronize)
         assert bool(torch.isfinite(buf).all()), "state went non-finite"
         eq.close()
         return wall, ev_ms, reps
