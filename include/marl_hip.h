@@ -55,7 +55,9 @@ int marl_synchronize(marl_ctx* ctx);
  *   the fused kernels takes its full transcendental path - the input-independent worst case, for benchmarks), radau_solver
  *   (linear systems of the implicit path: 0 block parallel cyclic reduction - the default -, 1 sequential block Thomas),
  *   rk4_stream (fixed-step RK4 of one grid as ONE dataflow launch over (level, tile) work items instead of one launch per
- *   fused level: 0 never, 1 - the default - for grids of 196 608 cells or more, 2 always; results are bit-identical). */
+ *   fused level: 0 never, 1 - the default - for grids of 196 608 cells or more, 2 always; results are bit-identical),
+ *   rk4_stream_test_raise (test hook: the next streamed run starts with its give-up flag raised - marl_synchronize must
+ *   report error -2 and the context must recover). */
 int marl_set_option(marl_ctx* ctx, const char* name, int64_t value);
 /* Derived constants of instance `inst` in the order of tests/golden/derived_constants.json:
  * delta_x nu1 nu2 KRat dCa dCO3 delta Da lambda_ auxcon rhorat0 rhorat presum F_fixed dPhi_fixed

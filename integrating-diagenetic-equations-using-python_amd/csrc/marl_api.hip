@@ -38,9 +38,12 @@ struct marl_ctx {
     size_t buf_cap[4] = {0, 0, 0, 0};
     double* part = nullptr;
     size_t part_cap = 0;
-    // streamed RK4 (rk4_stream_kernel): work queue {next item, abort flag} + one published-level counter per tile
+    // streamed RK4 (rk4_stream_kernel): item counter (+ one spare word) + one published-level counter per tile; never reset
+    // between launches - sq_item_base / sq_level_base say where they stand
     unsigned* sq = nullptr;
     size_t sq_cap = 0;
+    unsigned sq_item_base = 0, sq_level_base = 0;
+    bool sq_test_raise = false;    // test hook (option rk4_stream_test_raise): the next streamed run starts with the flag raised
     unsigned* sq_sticky = nullptr; // device: raised by a streamed run that gave up waiting; cleared by the host only
     unsigned* sq_host = nullptr;   // pinned: copy of sq_sticky
     bool sq_pending = false;       // streamed runs since sq_sticky was last looked at
@@ -284,6 +287,8 @@ static int stream_check(marl_ctx* ctx)
     ctx->sq_pending = false;
     if (*ctx->sq_host) {
         HIP_OK(ctx, hipMemsetAsync(ctx->sq_sticky, 0, sizeof(unsigned), ctx->stream));
+        if (ctx->sq) HIP_OK(ctx, hipMemsetAsync(ctx->sq, 0, ctx->sq_cap * sizeof(unsigned), ctx->stream));
+        ctx->sq_item_base = ctx->sq_level_base = 0;
         return fail(ctx, -2, "rk4: the streamed time loop gave up waiting for a neighbouring tile (rk4_stream_kernel); the state is invalid");
     }
     return 0;
@@ -307,6 +312,7 @@ int marl_set_option(marl_ctx* ctx, const char* name, int64_t value)
     else if (n == "poll_interval") ctx->poll = value > 0 ? value : 1;
     else if (n == "radau_solver") ctx->radau_solver = value ? 1 : 0;
     else if (n == "rk4_stream") ctx->rk4_stream = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (n == "rk4_stream_test_raise") ctx->sq_test_raise = value != 0;
     else if (n == "no_reuse") {
         // every evaluation of the fused kernels takes its full path (what a rough state does wave by wave): re-upload the constants
         for (auto& c : ctx->hconsts) c.hot.no_reuse = value ? 1 : 0;
@@ -457,10 +463,10 @@ static void launch_stream_t(marl_ctx* ctx, double* a, double* b, int layout, dou
 {
     if (layout == LAYOUT_TILED)
         hipLaunchKernelGGL((rk4_stream_kernel<256, LAYOUT_TILED, NSTEPS, VD>), dim3(blocks), dim3(256), 0, ctx->stream, a, b, ctx->dconsts, ctx->slab, dt,
-                           levels, tiles, ctx->sq, ctx->sq + 2, ctx->sq_sticky);
+                           levels, tiles, ctx->sq, ctx->sq + 2, ctx->sq_sticky, ctx->sq_item_base, ctx->sq_level_base);
     else
         hipLaunchKernelGGL((rk4_stream_kernel<256, LAYOUT_FIELD_MAJOR, NSTEPS, VD>), dim3(blocks), dim3(256), 0, ctx->stream, a, b, ctx->dconsts, ctx->slab,
-                           dt, levels, tiles, ctx->sq, ctx->sq + 2, ctx->sq_sticky);
+                           dt, levels, tiles, ctx->sq, ctx->sq + 2, ctx->sq_sticky, ctx->sq_item_base, ctx->sq_level_base);
 }
 
 static int rk4_stream(marl_ctx* ctx, double* a, double* b, int layout, double dt, int per, int64_t levels)
@@ -476,18 +482,25 @@ static int rk4_stream(marl_ctx* ctx, double* a, double* b, int layout, double dt
         HIP_OK(ctx, hipMalloc((void**)&ctx->sq_sticky, sizeof(unsigned)));
         HIP_OK(ctx, hipMemsetAsync(ctx->sq_sticky, 0, sizeof(unsigned), ctx->stream));
     }
-    if (ctx->sq_cap < (size_t)tiles + 2) {
-        if (ctx->sq) HIP_OK(ctx, hipFree(ctx->sq));
-        ctx->sq = nullptr;
-        ctx->sq_cap = 0;
-        HIP_OK(ctx, hipMalloc((void**)&ctx->sq, ((size_t)tiles + 2) * sizeof(unsigned)));
-        ctx->sq_cap = (size_t)tiles + 2;
+    if (ctx->sq_cap < (size_t)tiles + 2 || ctx->sq_level_base > (1u << 30)) {   // (re)start the counters
+        if (ctx->sq_cap < (size_t)tiles + 2) {
+            if (ctx->sq) HIP_OK(ctx, hipFree(ctx->sq));
+            ctx->sq = nullptr;
+            ctx->sq_cap = 0;
+            HIP_OK(ctx, hipMalloc((void**)&ctx->sq, ((size_t)tiles + 2) * sizeof(unsigned)));
+            ctx->sq_cap = (size_t)tiles + 2;
+        }
+        HIP_OK(ctx, hipMemsetAsync(ctx->sq, 0, ctx->sq_cap * sizeof(unsigned), ctx->stream));
+        ctx->sq_item_base = ctx->sq_level_base = 0;
+    }
+    if (ctx->sq_test_raise) {   // as if a workgroup of an earlier launch had given up: waiting workgroups leave, marl_synchronize reports
+        HIP_OK(ctx, hipMemsetAsync(ctx->sq_sticky, 1, sizeof(unsigned), ctx->stream));
+        ctx->sq_test_raise = false;
     }
     while (levels > 0) {
         // (the item counter is 32 bits wide; an even number of levels per launch keeps the ping-pong orientation)
         const int64_t cap = ((int64_t)0x7fffffff / tiles) & ~(int64_t)1;
         const int64_t lv = std::min<int64_t>(levels, std::max<int64_t>(cap, 2));
-        HIP_OK(ctx, hipMemsetAsync(ctx->sq, 0, ((size_t)tiles + 2) * sizeof(unsigned), ctx->stream));
         const unsigned blocks = (unsigned)std::min<int64_t>(lv * tiles, 4 * (int64_t)ctx->cus);   // 4 workgroups of 256 per CU are resident
         switch (per) {
             case 1: if (ctx->var_dphi) launch_stream_t<1, true>(ctx, a, b, layout, dt, (unsigned)lv, (unsigned)tiles, blocks);
@@ -503,6 +516,8 @@ static int rk4_stream(marl_ctx* ctx, double* a, double* b, int layout, double dt
         }
         LAUNCH_OK(ctx);
         ctx->sq_pending = true;
+        ctx->sq_item_base += (unsigned)(lv * tiles) + blocks;   // its items + one failing grab per workgroup (wraps with the counter)
+        ctx->sq_level_base += (unsigned)lv;
         levels -= lv;
         if (levels > 0 && (lv & 1)) std::swap(a, b);
     }

@@ -506,21 +506,25 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(CPT ==
 // and publishes its tile.  Ping-pong between two buffers is safe: neighbours can never be more than one level apart.
 //   * Progress: an item only waits for items with smaller numbers, which were handed out earlier to workgroups that are
 //     running - the smallest unfinished item never waits.  Every wait is bounded (STREAM_SPIN_LIMIT polls, ~1 s): on expiry,
-//     or when any workgroup has raised queue[1], the workgroup raises queue[1] and leaves; the host reports the error.
+//     or when any workgroup has raised the sticky flag, the workgroup raises it and leaves; the host reports the error.
 //   * Coherence: tiles cross XCDs (one L2 each).  A release fence at agent scope writes back the XCD's whole L2 (measured 4x
 //     slower, profiles/r02_lab_rk45_fused_control.log); instead the state itself moves with agent-scope (sc1: write-through /
-//     L2-bypassing) stores and loads, and a tile is published - done[tile] = level + 1, also sc1 - only after every thread's
+//     L2-bypassing) stores and loads, and a tile is published - done[tile] = level_base + level + 1, also sc1 - only after every thread's
 //     stores have been acknowledged (s_waitcnt vmcnt(0) + barrier).  The path is bound by the fp64 VALU, not by memory:
 //     80 MB per level through the Infinity Fabric instead of the L2s costs nothing measurable.
-// queue[0]: next item; queue[1]: abort flag; done[tiles]: levels published - all zero at launch.  sticky: raised with queue[1]
-// and never cleared by the device: the host looks at it at its next synchronisation point (marl_synchronize).
+// Nothing is reset between launches (a call is ONE launch, no memset in front of it): queue[0], the item counter, and done[t], the
+// levels tile t has published, only ever grow; a launch is told where they stand (item_base: every earlier launch took its
+// items plus one failing grab per workgroup; level_base: the levels of all earlier launches) and compares wrap-safely.  A stale
+// value can only be too SMALL - it makes a reader wait, never pass.  sticky: raised by a workgroup that gives up; checked by
+// waiting workgroups, never cleared by the device: the host looks at it at its next synchronisation point (marl_synchronize)
+// and then resets counters and bases.
 // ---------------------------------------------------------------------------------------------
 constexpr unsigned STREAM_SPIN_LIMIT = 1u << 19;
 
 template <int BLK, int LAYOUT, int NSTEPS, bool VD = false>
 __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8)))
 rk4_stream_kernel(double* bufA, double* bufB, const DevConsts* __restrict__ consts, Slab S, double dt, unsigned levels, unsigned tiles,
-                  unsigned* queue, unsigned* done, unsigned* sticky)
+                  unsigned* queue, unsigned* done, unsigned* sticky, unsigned item_base, unsigned level_base)
 {
     constexpr int CPT = 1;
     constexpr int H = 4 * NSTEPS;
@@ -541,7 +545,7 @@ rk4_stream_kernel(double* bufA, double* bufB, const DevConsts* __restrict__ cons
         // previous s_item - seen as partly stale tiles.  tools/lab_src, profiles/r02_lab_rk4_stream.log.)
         __syncthreads();
         if (threadIdx.x == 0) {
-            s_item = __hip_atomic_fetch_add(&queue[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_item = __hip_atomic_fetch_add(&queue[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - item_base;
             s_abort = 0;
         }
         __syncthreads();
@@ -553,11 +557,10 @@ rk4_stream_kernel(double* bufA, double* bufB, const DevConsts* __restrict__ cons
                 const int64_t t = (int64_t)tile - 1 + threadIdx.x;
                 if (t >= 0 && t < (int64_t)tiles) {
                     unsigned spins = 0;
-                    while (__hip_atomic_load(&done[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < level) {
+                    while ((int)(__hip_atomic_load(&done[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (level_base + level)) < 0) {
                         __builtin_amdgcn_s_sleep(4);
                         if (++spins > STREAM_SPIN_LIMIT ||
-                            ((spins & 255u) == 0 && __hip_atomic_load(&queue[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                            __hip_atomic_store(&queue[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ((spins & 255u) == 0 && __hip_atomic_load(sticky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                             __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             s_abort = 1;
                             break;
@@ -588,7 +591,7 @@ rk4_stream_kernel(double* bufA, double* bufB, const DevConsts* __restrict__ cons
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         __syncthreads();                 // ... and everybody else's (and everybody has read s_item, s_abort)
         if (threadIdx.x == 0) {
-            __hip_atomic_store(&done[tile], level + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&done[tile], level_base + level + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

@@ -201,6 +201,37 @@ def test_rk4_streamed_loop_is_bit_identical_to_per_level_launches(torch_cuda, N,
     eq.close()
 
 
+def test_rk4_streamed_loop_reports_a_raised_flag_and_recovers(torch_cuda):
+    """The streamed loop's safety net: a workgroup that gives up waiting raises a device flag, waiting workgroups leave, and the
+    asynchronous entry point's error surfaces at marl_synchronize (error -2, "the state is invalid"); the context then resets its
+    counters and the next run is bit-identical to per-level launches again.  (The flag is raised through the test hook.)"""
+    torch = torch_cuda
+    from marlpde_amd._abi import MarlError
+    N, nsteps, layout = 300001, 24, 1
+    p = scenario("default", N)
+    eq = make_model(p)
+    eq.use_stream(torch.cuda.current_stream().cuda_stream)
+    y = synthetic_state(p, N, amplitude=0.02)
+    dt = 0.25 * (eq.Depths.length / N) ** 2
+    yd = torch.from_numpy(y).cuda()
+    buf = torch.zeros(eq.state_doubles(layout), dtype=torch.float64, device="cuda")
+
+    def run(stream):
+        eq.set_option("rk4_stream", stream)
+        eq.convert_layout_device(yd.data_ptr(), buf.data_ptr(), 0, layout)
+        eq.integrate_rk4_device(buf.data_ptr(), dt, nsteps, layout)
+        eq.synchronize()
+        return buf.clone()
+    ref = run(0)
+    assert torch.equal(run(1), ref)
+    eq.set_option("rk4_stream_test_raise", 1)
+    with pytest.raises(MarlError, match="state is invalid"):
+        run(1)
+    for _ in range(3):
+        assert torch.equal(run(1), ref)
+    eq.close()
+
+
 @pytest.mark.parametrize("name,N", [("default", 200), ("A", 200), ("matlab", 1024), ("stiffphi", 64), ("A", 3000)])
 def test_rk4_host_entry_against_oracle(oracle, name, N):
     """marl_integrate_rk4 (host pointers): small grids take the one-workgroup on-chip path, larger ones the fused path."""
