@@ -70,6 +70,7 @@ struct marl_ctx {
     // options
     int64_t rk4_variant = -1, rk45_variant = -1, sweep_variant = -1, host_layout = LAYOUT_TILED, poll = 64;
     int64_t rk4_stream = 1;     // the fixed-step loop of one grid as ONE dataflow launch (rk4_stream_kernel): 0 never, 1 large grids, 2 always
+    int64_t radau_fused_solve = 1;   // small systems (5 N <= 2048): all PCR levels of a solve in one launch
     int64_t radau_solver = 0;   // 0: block parallel cyclic reduction (parallel over depth); 1: sequential block Thomas
     std::string err;
 };
@@ -311,6 +312,7 @@ int marl_set_option(marl_ctx* ctx, const char* name, int64_t value)
     else if (n == "host_layout") ctx->host_layout = value ? LAYOUT_TILED : LAYOUT_FIELD_MAJOR;
     else if (n == "poll_interval") ctx->poll = value > 0 ? value : 1;
     else if (n == "radau_solver") ctx->radau_solver = value ? 1 : 0;
+    else if (n == "radau_fused_solve") ctx->radau_fused_solve = value ? 1 : 0;
     else if (n == "rk4_stream") ctx->rk4_stream = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "rk4_stream_test_raise") ctx->sq_test_raise = value != 0;
     else if (n == "no_reuse") {
@@ -1428,6 +1430,12 @@ int radau_solve(marl_ctx* ctx, RadauWork& w, bool both)
         LAUNCH_OK(ctx);
         return 0;
     }
+    if (n <= radau::PCR_FUSED_MAX && ctx->radau_fused_solve) {   // small systems: every level in one launch
+        hipLaunchKernelGGL(radau::pcr_solve_fused_kernel, dim3(1, both ? 2 : 1), dim3(radau::PCR_FUSED_THREADS), 0, ctx->stream, N, w.nlevels, 0, w.Sr, w.Sc,
+                           w.rhs_r, w.rhs_r, w.rhs_c, w.rhs_c);
+        LAUNCH_OK(ctx);
+        return 0;
+    }
     const dim3 grid(blocks256(n), both ? 2 : 1);
     // ping-pong: rhs -> b[0] -> b[1] -> ... ; the last launch (x = D^-1 b) writes back into rhs
     const double* in_r = w.rhs_r;
@@ -1926,15 +1934,21 @@ extern "C" int marl_sweep_radau_dev(marl_ctx* ctx, double* y_dev, double t0, dou
                 hipLaunchKernelGGL(error_rhs_batch_kernel, dim3(gx, 1, cnt), b256, 0, ctx->stream, w.f, w.tmp, w.Z, w.y, N, E3[0], E3[1], E3[2], w.rhs_r, w.ynew, zb);
                 RB_OK();
             }
-            const double* in_r = w.rhs_r;
-            const cplx* in_c = w.rhs_c;
-            for (int level = 0; level <= w.nlevels; level++) {
-                double* out_r = (level == w.nlevels) ? w.rhs_r : w.Sr.b[level & 1];
-                cplx* out_c = (level == w.nlevels) ? w.rhs_c : w.Sc.b[level & 1];
-                hipLaunchKernelGGL(pcr_solve_kernel, dim3(gx, which == 0 ? 2 : 1, cnt), b256, 0, ctx->stream, N, level, w.nlevels, 0, w.Sr, w.Sc, in_r, out_r, in_c, out_c, zb);
+            if (n <= PCR_FUSED_MAX && ctx->radau_fused_solve) {
+                hipLaunchKernelGGL(pcr_solve_fused_kernel, dim3(1, which == 0 ? 2 : 1, cnt), dim3(PCR_FUSED_THREADS), 0, ctx->stream, N, w.nlevels, 0, w.Sr, w.Sc, w.rhs_r,
+                                   w.rhs_r, w.rhs_c, w.rhs_c, zb);
                 RB_OK();
-                in_r = out_r;
-                in_c = out_c;
+            } else {
+                const double* in_r = w.rhs_r;
+                const cplx* in_c = w.rhs_c;
+                for (int level = 0; level <= w.nlevels; level++) {
+                    double* out_r = (level == w.nlevels) ? w.rhs_r : w.Sr.b[level & 1];
+                    cplx* out_c = (level == w.nlevels) ? w.rhs_c : w.Sc.b[level & 1];
+                    hipLaunchKernelGGL(pcr_solve_kernel, dim3(gx, which == 0 ? 2 : 1, cnt), b256, 0, ctx->stream, N, level, w.nlevels, 0, w.Sr, w.Sc, in_r, out_r, in_c, out_c, zb);
+                    RB_OK();
+                    in_r = out_r;
+                    in_c = out_c;
+                }
             }
             if (which == 0)
                 hipLaunchKernelGGL(newton_update_batch_kernel, dim3(1, 1, cnt), dim3(1024), 0, ctx->stream, w.y, w.rhs_r, w.rhs_c, w.scale, N, w.W, w.Z, w.YS, dctl, zb);

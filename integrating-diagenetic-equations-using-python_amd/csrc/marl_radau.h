@@ -38,6 +38,17 @@ __device__ inline double abs1(double a) { return fabs(a); }
 __device__ inline double abs1(cplx a) { return fabs(a.re) + fabs(a.im); }   // LAPACK's cabs1
 __device__ inline double recip(double a) { return 1.0 / a; }
 __device__ inline cplx recip(cplx a) { const double d = 1.0 / (a.re * a.re + a.im * a.im); return {a.re * d, -a.im * d}; }
+// acc + a b and a b with the contraction spelled out: the solve kernels (one launch per level / all levels in one launch) must round
+// alike, and left to itself the compiler contracts the complex multiply-adds differently from kernel to kernel
+__device__ __forceinline__ double madd(double acc, double a, double b) { return __builtin_fma(a, b, acc); }
+// (the form the compiler chose for the per-level kernel, whose results the implicit path's tests were pinned with)
+__device__ __forceinline__ cplx mul1(cplx a, cplx b) { return {__builtin_fma(a.re, b.re, -(a.im * b.im)), __builtin_fma(a.im, b.re, a.re * b.im)}; }
+__device__ __forceinline__ cplx madd(cplx acc, cplx a, cplx b)
+{
+    const cplx p = mul1(a, b);
+    return {acc.re + p.re, acc.im + p.im};
+}
+__device__ __forceinline__ double mul1(double a, double b) { return a * b; }
 __device__ inline double lift(double a, double) { return a; }
 __device__ inline cplx lift(double a, cplx) { return {a, 0.0}; }
 
@@ -507,19 +518,19 @@ __device__ __forceinline__ void pcr_solve_row(int64_t N, int64_t kk, int level, 
         if (i - s >= 0) {
             const T* al = S.alpha + ((int64_t)level * N + i) * 25 + r * NF;
 #pragma unroll
-            for (int k = 0; k < NF; k++) acc = acc + al[k] * bin[(i - s) * NF + k];
+            for (int k = 0; k < NF; k++) acc = madd(acc, al[k], bin[(i - s) * NF + k]);
         }
         if (i + s < N) {
             const T* ga = S.gamma + ((int64_t)level * N + i) * 25 + r * NF;
 #pragma unroll
-            for (int k = 0; k < NF; k++) acc = acc + ga[k] * bin[(i + s) * NF + k];
+            for (int k = 0; k < NF; k++) acc = madd(acc, ga[k], bin[(i + s) * NF + k]);
         }
         bout[kk] = acc;
     } else {   // x_i = D_i^-1 b_i
         const T* di = ((nlevels & 1) ? S.Dinv[1] : S.Dinv[0]) + i * 25 + r * NF;
-        T acc = di[0] * bin[i * NF];
+        T acc = mul1(di[0], bin[i * NF]);
 #pragma unroll
-        for (int k = 1; k < NF; k++) acc = acc + di[k] * bin[i * NF + k];
+        for (int k = 1; k < NF; k++) acc = madd(acc, di[k], bin[i * NF + k]);
         bout[kk] = acc;
     }
 }
@@ -536,6 +547,43 @@ __global__ void __launch_bounds__(256) pcr_solve_kernel(int64_t N, int level, in
     if (kk >= NF * N) return;
     if (blockIdx.y + first == 0) pcr_solve_row<double>(N, kk, level, nlevels, Sr, bin_r, bout_r);
     else pcr_solve_row<cplx>(N, kk, level, nlevels, Sc, bin_c, bout_c);
+}
+
+// All levels of a solve in ONE launch for small systems (5 N <= PCR_FUSED_MAX unknowns - the N = 200 grids of the reference's own
+// runs and of scenario sweeps): one workgroup per (instance, system) keeps the right-hand side in LDS and steps through the levels
+// with a barrier between them - the same recurrences in the same order as the per-level kernel (bit-identical results), 1 launch
+// instead of 1 + ceil(log2 N) per Newton iteration.
+constexpr int PCR_FUSED_MAX = 2048;
+constexpr int PCR_FUSED_THREADS = 1024;
+
+template <class T>
+__device__ __forceinline__ void pcr_solve_all(int64_t N, int nlevels, const PcrSystem<T>& S, const T* __restrict__ bin, T* __restrict__ bout, T* lds)
+{
+    const int n = (int)(NF * N);
+    for (int k = threadIdx.x; k < n; k += PCR_FUSED_THREADS) lds[k] = bin[k];
+    __syncthreads();
+    int cur = 0;
+    for (int level = 0; level < nlevels; level++) {
+        const T* b = lds + cur * PCR_FUSED_MAX;
+        T* o = lds + (cur ^ 1) * PCR_FUSED_MAX;
+        for (int k = threadIdx.x; k < n; k += PCR_FUSED_THREADS) pcr_solve_row<T>(N, k, level, nlevels, S, b, o);
+        __syncthreads();
+        cur ^= 1;
+    }
+    for (int k = threadIdx.x; k < n; k += PCR_FUSED_THREADS) pcr_solve_row<T>(N, k, nlevels, nlevels, S, lds + cur * PCR_FUSED_MAX, bout);
+}
+
+// blockIdx.y + first: which system (0 real, 1 complex); in place (bout == bin) is fine: the input is staged in LDS first
+__global__ void __launch_bounds__(PCR_FUSED_THREADS) pcr_solve_fused_kernel(int64_t N, int nlevels, int first, PcrSystem<double> Sr, PcrSystem<cplx> Sc,
+                                                                            const double* bin_r, double* bout_r, const cplx* bin_c, cplx* bout_c,
+                                                                            ZBatch B = ZBatch{0, nullptr, 0, 0, nullptr})
+{
+    if (z_masked_out(B)) return;
+    Sr = z_shift_system(Sr, B); Sc = z_shift_system(Sc, B);
+    bin_r = z_shift(bin_r, B); bout_r = z_shift(bout_r, B); bin_c = z_shift(bin_c, B); bout_c = z_shift(bout_c, B);
+    __shared__ cplx lds[2 * PCR_FUSED_MAX];   // (the real system uses half of the bytes)
+    if (blockIdx.y + first == 0) pcr_solve_all<double>(N, nlevels, Sr, bin_r, bout_r, reinterpret_cast<double*>(lds));
+    else pcr_solve_all<cplx>(N, nlevels, Sc, bin_c, bout_c, lds);
 }
 
 // ---- element-wise pieces of solve_collocation_system (radau.py:47-130) and _step_impl (:404-537) -------------------------
