@@ -201,6 +201,29 @@ def test_rk4_streamed_loop_is_bit_identical_to_per_level_launches(torch_cuda, N,
     eq.close()
 
 
+def test_rk4_streamed_loop_with_time_varying_porosity_diffusion(torch_cuda, oracle):
+    """The dPhi_variable instantiation of the streamed loop (rk4_stream_kernel<..., VD = true>): against the oracle, and bit-identical
+    to per-level launches."""
+    torch = torch_cuda
+    N, nsteps = 5003, 4 * 5 + 1
+    p = scenario("default", N, dPhi_variable=True)
+    eq = make_model(p)
+    eq.use_stream(torch.cuda.current_stream().cuda_stream)
+    y = synthetic_state(p, N, amplitude=0.02)
+    dt = 0.2 * (eq.Depths.length / N) ** 2
+    ref = oracle.rk4(oracle.params_from_model(eq), N, y, dt, nsteps)
+    out = []
+    for stream in (0, 2, 2):
+        eq.set_option("rk4_stream", stream)
+        yd = torch.from_numpy(y).cuda()
+        eq.integrate_rk4_device(yd.data_ptr(), dt, nsteps, 0)
+        eq.synchronize()
+        out.append(yd.cpu().numpy())
+    assert rel_to_max(out[0], ref) <= RUN_TOL
+    assert np.array_equal(out[1], out[0]) and np.array_equal(out[2], out[0])
+    eq.close()
+
+
 def test_rk4_streamed_loop_reports_a_raised_flag_and_recovers(torch_cuda):
     """The streamed loop's safety net: a workgroup that gives up waiting raises a device flag, waiting workgroups leave, and the
     asynchronous entry point's error surfaces at marl_synchronize (error -2, "the state is invalid"); the context then resets its
