@@ -57,7 +57,8 @@ int marl_synchronize(marl_ctx* ctx);
  *   rk4_stream (fixed-step RK4 of one grid as ONE dataflow launch over (level, tile) work items instead of one launch per
  *   fused level: 0 never, 1 - the default - for grids of 196 608 cells or more, 2 always; results are bit-identical),
  *   rk4_stream_test_raise (test hook: the next streamed run starts with its give-up flag raised - marl_synchronize must
- *   report error -2 and the context must recover). */
+ *   report error -2 and the context must recover), rk4_stream_max_items (test hook: work items per streamed launch, default
+ *   2^31 - 1: a call with more (level, tile) items is split into several launches of an even number of levels). */
 int marl_set_option(marl_ctx* ctx, const char* name, int64_t value);
 /* Derived constants of instance `inst` in the order of tests/golden/derived_constants.json:
  * delta_x nu1 nu2 KRat dCa dCO3 delta Da lambda_ auxcon rhorat0 rhorat presum F_fixed dPhi_fixed

@@ -44,6 +44,7 @@ struct marl_ctx {
     size_t sq_cap = 0;
     unsigned sq_item_base = 0, sq_level_base = 0;
     bool sq_test_raise = false;    // test hook (option rk4_stream_test_raise): the next streamed run starts with the flag raised
+    int64_t sq_max_items = 0x7fffffff;   // items per launch (the counter is 32 bits wide); test hook rk4_stream_max_items lowers it
     unsigned* sq_sticky = nullptr; // device: raised by a streamed run that gave up waiting; cleared by the host only
     unsigned* sq_host = nullptr;   // pinned: copy of sq_sticky
     bool sq_pending = false;       // streamed runs since sq_sticky was last looked at
@@ -315,6 +316,7 @@ int marl_set_option(marl_ctx* ctx, const char* name, int64_t value)
     else if (n == "radau_fused_solve") ctx->radau_fused_solve = value ? 1 : 0;
     else if (n == "rk4_stream") ctx->rk4_stream = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "rk4_stream_test_raise") ctx->sq_test_raise = value != 0;
+    else if (n == "rk4_stream_max_items") ctx->sq_max_items = value > 0 ? std::min<int64_t>(value, 0x7fffffff) : 0x7fffffff;
     else if (n == "no_reuse") {
         // every evaluation of the fused kernels takes its full path (what a rough state does wave by wave): re-upload the constants
         for (auto& c : ctx->hconsts) c.hot.no_reuse = value ? 1 : 0;
@@ -501,7 +503,7 @@ static int rk4_stream(marl_ctx* ctx, double* a, double* b, int layout, double dt
     }
     while (levels > 0) {
         // (the item counter is 32 bits wide; an even number of levels per launch keeps the ping-pong orientation)
-        const int64_t cap = ((int64_t)0x7fffffff / tiles) & ~(int64_t)1;
+        const int64_t cap = (ctx->sq_max_items / tiles) & ~(int64_t)1;
         const int64_t lv = std::min<int64_t>(levels, std::max<int64_t>(cap, 2));
         const unsigned blocks = (unsigned)std::min<int64_t>(lv * tiles, 4 * (int64_t)ctx->cus);   // 4 workgroups of 256 per CU are resident
         switch (per) {

@@ -201,6 +201,31 @@ def test_rk4_streamed_loop_is_bit_identical_to_per_level_launches(torch_cuda, N,
     eq.close()
 
 
+@pytest.mark.parametrize("N,variant,nsteps,max_items", [(5003, 2, 4 * 11 + 1, 100), (5003, 2, 4 * 12, 60), (150, 2, 4 * 6, 0), (230, 0, 7, 0)])
+def test_rk4_streamed_loop_split_launches_and_single_tile(torch_cuda, N, variant, nsteps, max_items):
+    """A call with more (level, tile) items than the 32-bit item counter may hand out in one launch is split into launches of an
+    even number of levels (forced here through the test hook rk4_stream_max_items: 23 tiles, 4 / 2 levels per launch, 11 / 12
+    levels in all); and grids of one or two tiles (no left / right producer to wait for) - all bit-identical to per-level launches."""
+    torch = torch_cuda
+    p = scenario("default", N)
+    eq = make_model(p)
+    eq.use_stream(torch.cuda.current_stream().cuda_stream)
+    eq.set_option("rk4_variant", variant)
+    y = synthetic_state(p, N, amplitude=0.02)
+    dt = 0.25 * (eq.Depths.length / N) ** 2
+    out = []
+    for stream in (0, 2, 2):
+        eq.set_option("rk4_stream", stream)
+        eq.set_option("rk4_stream_max_items", max_items)
+        yd = torch.from_numpy(y).cuda()
+        eq.integrate_rk4_device(yd.data_ptr(), dt, nsteps, 0)
+        eq.synchronize()
+        out.append(yd.cpu().numpy())
+    assert np.all(np.isfinite(out[0]))
+    assert np.array_equal(out[1], out[0]) and np.array_equal(out[2], out[0])
+    eq.close()
+
+
 def test_rk4_streamed_loop_with_time_varying_porosity_diffusion(torch_cuda, oracle):
     """The dPhi_variable instantiation of the streamed loop (rk4_stream_kernel<..., VD = true>): against the oracle, and bit-identical
     to per-level launches."""
