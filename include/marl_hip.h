@@ -54,6 +54,8 @@ int marl_synchronize(marl_ctx* ctx);
  *   host-pointer entry points), poll_interval (attempts enqueued between status reads), no_reuse (1: every RHS evaluation of
  *   the fused kernels takes its full transcendental path - the input-independent worst case, for benchmarks), radau_solver
  *   (linear systems of the implicit path: 0 block parallel cyclic reduction - the default -, 1 sequential block Thomas),
+ *   radau_fused_solve (1, the default: systems of up to 2048 unknowns run every cyclic-reduction level of a solve in one
+ *   launch; 0: one launch per level - bit-identical),
  *   rk4_stream (fixed-step RK4 of one grid as ONE dataflow launch over (level, tile) work items instead of one launch per
  *   fused level: 0 never, 1 - the default - for grids of 196 608 cells or more, 2 always; results are bit-identical),
  *   rk4_stream_test_raise (test hook: the next streamed run starts with its give-up flag raised - marl_synchronize must
