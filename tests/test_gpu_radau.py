@@ -203,3 +203,38 @@ def test_radau_sweep_equals_instance_by_instance(torch_cuda_radau, oracle):
     # the first two are the reference's regression cases: final profiles within its tolerances of its HDF5 data
     gold = np.load(f"{GOLDEN}/ref_final_scenarioA_Phi0_0.6_PhiIni_0.5.npy")
     np.testing.assert_allclose(got[0].reshape(5, N), gold, rtol=0.1, atol=0.01)
+
+
+def test_radau_sweep_of_512_scenarios_properties(torch_cuda_radau):
+    """A sweep the size bench.py reports (512 scenarios over Phi0 x PhiIni x k3 = k4, N = 200, to T*): every instance reaches T* with
+    finite fields (positive porosity and concentrations), its statistics are in the range single runs show, and a sample of instances agrees with the same scenario
+    integrated alone at the reference's tolerance (tests/Regression_test/test_regression.py:29-30)."""
+    torch = torch_cuda_radau
+    from dataclasses import asdict
+    from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
+    from marlpde_amd.parameters import Map_Scenario
+    N, B, k = 200, 512, 8
+    base = asdict(Map_Scenario()) | {"N": N}
+    inst = []
+    for i in range(B):
+        d = {"Phi0": 0.5 + 0.2 * ((i % k) / (k - 1)), "PhiIni": 0.5 + 0.2 * (((i // k) % k) / (k - 1)), "k3": 10 ** (-2 + ((i // (k * k)) % k) / (k - 1))}
+        d["PhiNR"], d["k4"] = d["PhiIni"], d["k3"]
+        inst.append(d)
+    y0 = np.stack([np.concatenate([np.full(N, (base | d)[q]) for q in ("CAIni", "CCIni", "cCaIni", "cCO3Ini", "PhiIni")]) for d in inst])
+    eq = LMAHeureuxPorosityDiff.from_scenario(base, device=0, instances=inst)
+    eq.use_stream(torch.cuda.current_stream().cuda_stream)
+    yd = torch.from_numpy(y0).cuda()
+    res = eq.sweep_radau_device(yd.data_ptr(), (0.0, 1.0), 1e-6, 1e-3, 1e-3)
+    got = yd.cpu().numpy().reshape(B, 5, N)
+    eq.close()
+    assert all(r.status == 0 and r.t_reached == 1.0 for r in res)
+    assert np.all(np.isfinite(got))
+    print("porosity range", got[:, 4].min(), got[:, 4].max(), "solids range", got[:, :2].min(), (got[:, 0] + got[:, 1]).max())
+    assert np.all(got[:, 4] > 0) and np.all(got[:, 2:4] > 0)               # porosity and solute concentrations stay positive
+    nfev = np.array([r.nfev for r in res])
+    assert 200 < np.median(nfev) < 600 and nfev.min() > 150
+    for b in range(0, B, 73):
+        one = LMAHeureuxPorosityDiff.from_scenario(base | inst[b], device=0)
+        ref = one.integrate_radau(y0[b], (0.0, 1.0), 1e-6, 1e-3, 1e-3, events=False)
+        one.close()
+        np.testing.assert_allclose(got[b].ravel(), ref.y_final, rtol=0.1, atol=0.01)
