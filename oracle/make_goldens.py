@@ -250,6 +250,36 @@ def gen_radau(skip_slow):
               f"events {nev.tolist()} {time.time() - t_start:.1f}s")
 
 
+def gen_bdf():
+    """The other implicit method the reference's Solver names for its jac_sparsity (marlpde/parameters.py:205-219): scipy BDF on the
+    reference RHS, called like gen_radau calls Radau.  Cases: Scenario A and the Matlab cross-check case at the reference's N = 200,
+    one short tight-tolerance run."""
+    cases = [("A", SCENARIOS["A"], 200, {}, (0, 1)),
+             ("matlab", SCENARIOS["matlab"], 200, {}, (0, 1)),
+             ("A_N64_tight", SCENARIOS["A"], 64, {"rtol": 1e-6, "atol": 1e-8}, (0, 0.02))]
+    from marlpde.parameters import jacobian_sparsity
+    for name, ov, N, sov, span in cases:
+        eq, y0, p, _ = build_model(ov, N, 1)
+        eq.last_t = 0.0
+        sp = asdict(Solver()) | sov | {"t_span": span, "method": "BDF"}
+        sp.pop("backend", None)
+        for k in ("lband", "uband"):
+            sp.pop(k, None)
+        sp["jac_sparsity"] = jacobian_sparsity() if N == 200 else _sparsity(N)
+        t_start = time.time()
+        sp["dense_output"] = True
+        with np.errstate(all="ignore"):
+            sol = solve_ivp(eq.fun_numba, y0=y0, **sp, t_eval=np.array(span, dtype=float),
+                            events=[getattr(eq, e) for e in EVENTS], args=[_Bar(), (span[1] - span[0]) / 100000, span[0]])
+        tev, nev = _pack_events(sol.t_events)
+        np.savez_compressed(os.path.join(OUT, f"bdf_traj_{name}.npz"), y0=y0, N=N, t_span=np.array(span, dtype=float),
+                            rtol=sp["rtol"], atol=sp["atol"], first_step=sp["first_step"], step_times=np.asarray(sol.sol.ts),
+                            y_final=sol.y[:, -1], nfev=sol.nfev, njev=sol.njev, nlu=sol.nlu, status=sol.status,
+                            t_events=tev, n_events=nev, overrides=json.dumps(ov))
+        print(f"bdf {name}: {len(sol.sol.ts) - 1} steps, nfev {sol.nfev} njev {sol.njev} nlu {sol.nlu} status {sol.status} "
+              f"events {nev.tolist()} {time.time() - t_start:.1f}s")
+
+
 def _sparsity(N):
     """The reference's jacobian_sparsity() is hard-wired to the default N; the same pattern for another N
     (marlpde/parameters.py:150-199: 27 diagonals, CA/CC rows x Phi columns zeroed)."""
@@ -318,11 +348,12 @@ def gen_stub_pin(skip_slow):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-slow", action="store_true")
-    ap.add_argument("--only", default="", help="comma list of groups: params,rhs,h5,stubpin,rk45,rk45event,radau")
+    ap.add_argument("--only", default="", help="comma list of groups: params,rhs,h5,stubpin,rk45,rk45event,radau,bdf")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     groups = {"params": gen_params, "rhs": gen_rhs, "h5": gen_ref_h5, "stubpin": lambda: gen_stub_pin(args.skip_slow),
-              "rk45": lambda: gen_rk45(args.skip_slow), "rk45event": gen_rk45_event, "radau": lambda: gen_radau(args.skip_slow)}
+              "rk45": lambda: gen_rk45(args.skip_slow), "rk45event": gen_rk45_event, "radau": lambda: gen_radau(args.skip_slow),
+              "bdf": gen_bdf}
     for g in (args.only.split(",") if args.only else groups):
         groups[g]()
 

@@ -304,12 +304,27 @@ typedef struct {
     const double *K; /* 7 x 5N (Dormand-Prince stages), or NULL */
     double *scratch; /* 5N */
     const double *Q; /* Radau: 5N x 3 (RadauDenseOutput, radau.py:549-572), or NULL */
+    const double *D; /* BDF: (order + 1) x 5N differences (BdfDenseOutput, bdf.py:456-478), or NULL; then t_old / h hold t / h */
+    int order;
 } orc_dense;
 
 /* RkDenseOutput._call_impl, rk.py:560-574:  y(t) = y_old + h * Q . [x, x^2, x^3, x^4],  Q = K^T P */
 static void orc_dense_eval(const orc_dense *d, double t, double *out)
 {
     const int64_t n = NF * d->N;
+    if (d->D) { /* BdfDenseOutput._call_impl: x_j = (t - (t_end - h j)) / (h (1 + j)), p = cumprod(x), y = D[0] + D[1:].T . p */
+        double pr[8], acc = 1;
+        for (int j = 0; j < d->order; j++) {
+            acc *= (t - (d->t_old - d->h * j)) / (d->h * (1 + j));
+            pr[j] = acc;
+        }
+        for (int64_t i = 0; i < n; i++) {
+            double a = 0;
+            for (int j = 0; j < d->order; j++) a += d->D[(int64_t)(j + 1) * n + i] * pr[j];
+            out[i] = a + d->D[i];
+        }
+        return;
+    }
     const double x = (t - d->t_old) / d->h;
     if (d->Q) { /* RadauDenseOutput._call_impl, radau.py:557-572: y = Q . [x, x^2, x^3] + y_old  (not multiplied by h) */
         const double p1 = x, p2 = p1 * x, p3 = p2 * x; /* np.cumprod */
@@ -468,7 +483,7 @@ int marl_oracle_rk45(const marl_params *p, int64_t N, double *y, double t0, doub
         if (step_times && steps_out < max_steps_out) step_times[steps_out] = t;
         steps_out++;
 
-        orc_dense dense = {p, &c, N, t_old, h, yold, K, scratch, NULL};
+        orc_dense dense = {p, &c, N, t_old, h, yold, K, scratch, NULL, NULL, 0};
         /* events, ivp.py:673-694 + find_active_events :131-156 (direction 0, non-terminal) */
         orc_events(p, &c, N, y, g_new);
         for (int e = 0; e < MARL_NEVENTS; e++) {
@@ -1044,7 +1059,7 @@ int marl_oracle_radau(const marl_params *p, int64_t N, double *y, double t0, dou
         if (step_times && steps_out < max_steps_out) step_times[steps_out] = t;
         steps_out++;
 
-        orc_dense dense = {p, &c, N, t_old, sol_h, yold, NULL, scratch, Q};
+        orc_dense dense = {p, &c, N, t_old, sol_h, yold, NULL, scratch, Q, NULL, 0};
         orc_events(p, &c, N, y, g_new);
         for (int e = 0; e < MARL_NEVENTS; e++) {
             const int up = (g[e] <= 0) && (g_new[e] >= 0), down = (g[e] >= 0) && (g_new[e] <= 0);
@@ -1066,5 +1081,296 @@ int marl_oracle_radau(const marl_params *p, int64_t N, double *y, double t0, dou
     orc_events(p, &c, N, y, st->event_value);
     if (n_steps_out) *n_steps_out = steps_out;
     free(buf); free(R.J); free(R.factor); free(R.own_groups); free(ab_r); free(ab_c); free(rhs_c); free(piv_r); free(piv_c); free(rhs_r);
+    return status;
+}
+
+
+/* =============================================================================================================================
+ * scipy.integrate.solve_ivp(method="BDF", jac_sparsity=...) restated (scipy/integrate/_ivp/bdf.py; driver ivp.py:654-723): the
+ * variable-order (1..5) quasi-constant-step NDF method the reference's Solver offers next to its default Radau
+ * (marlpde/parameters.py:205-219: "Radau" and "BDF" take the jac_sparsity).  TEST INFRASTRUCTURE like the rest of this file.
+ * Shares the finite-difference Jacobian (rd_num_jac) and the banded LU with the Radau restatement above; the matrix is I - c J.
+ * ============================================================================================================================= */
+#define BDF_MAX_ORDER 5
+#define BDF_NEWTON_MAXITER 4
+
+/* compute_R (bdf.py:18-25): M[0][:] = 1, M[i][j] = (i - 1 - factor j) / i for i, j >= 1; R = cumprod(M, axis = 0) */
+static void bdf_compute_R(int order, double factor, double R[BDF_MAX_ORDER + 1][BDF_MAX_ORDER + 1])
+{
+    for (int j = 0; j <= order; j++) R[0][j] = 1;
+    for (int i = 1; i <= order; i++) {
+        R[i][0] = 0; /* M[i][0] = 0: the cumulative product of column 0 is 1, 0, 0, ... */
+        for (int j = 1; j <= order; j++) R[i][j] = R[i - 1][j] * ((i - 1 - factor * j) / i);
+    }
+}
+
+/* change_D (bdf.py:28-33): D[:order + 1] = (R U)^T D[:order + 1] */
+static void bdf_change_D(double *D, int64_t n, int order, double factor)
+{
+    double R[BDF_MAX_ORDER + 1][BDF_MAX_ORDER + 1], U[BDF_MAX_ORDER + 1][BDF_MAX_ORDER + 1], RU[BDF_MAX_ORDER + 1][BDF_MAX_ORDER + 1];
+    bdf_compute_R(order, factor, R);
+    bdf_compute_R(order, 1.0, U);
+    for (int i = 0; i <= order; i++)
+        for (int j = 0; j <= order; j++) {
+            double a = 0;
+            for (int k = 0; k <= order; k++) a += R[i][k] * U[k][j];
+            RU[i][j] = a;
+        }
+    for (int64_t e = 0; e < n; e++) {
+        double d[BDF_MAX_ORDER + 1], o[BDF_MAX_ORDER + 1];
+        for (int j = 0; j <= order; j++) d[j] = D[(int64_t)j * n + e];
+        for (int k = 0; k <= order; k++) {
+            double a = 0;
+            for (int j = 0; j <= order; j++) a += RU[j][k] * d[j];
+            o[k] = a;
+        }
+        for (int k = 0; k <= order; k++) D[(int64_t)k * n + e] = o[k];
+    }
+}
+
+/* band storage of  I - c J  in the cell-major ordering 5 i + f */
+static void bdf_assemble(const rd_ctx *R, double cc, double *ab)
+{
+    const int64_t n = R->n, N = R->N;
+    memset(ab, 0, sizeof(double) * (size_t)(RD_LDAB * n));
+    for (int64_t i = 0; i < N; i++)
+        for (int d = 0; d < 3; d++) {
+            const int64_t ic = i + d - 1;
+            if (ic < 0 || ic >= N) continue;
+            for (int f = 0; f < NF; f++)
+                for (int fp = 0; fp < NF; fp++) {
+                    const int64_t r = NF * i + f, c = NF * ic + fp;
+                    ab[RD_KV + r - c + c * RD_LDAB] = (r == c ? 1.0 : 0.0) - cc * R->J[((i * 3 + d) * NF + f) * NF + fp];
+                }
+        }
+}
+
+/* norm(coef * v / scale), common.py:63-65 */
+static double bdf_norm(const double *v, double coef, const double *scale, int64_t n)
+{
+    double s = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const double e = coef * v[i] / scale[i];
+        s += e * e;
+    }
+    return sqrt(s) / sqrt((double)n);
+}
+
+int marl_oracle_bdf(const marl_params *p, int64_t N, double *y, double t0, double t1, double first_step,
+                    double rtol, double atol, const int32_t *groups,
+                    const double *t_eval, int64_t n_eval, double *y_eval,
+                    double *step_times, int64_t max_steps_out, int64_t *n_steps_out,
+                    double *t_events, int64_t max_events, int64_t max_attempts, marl_stats *st)
+{
+    orc_consts c;
+    orc_derive(p, N, &c);
+    const int64_t n = NF * N;
+    memset(st, 0, sizeof *st);
+    if (rtol < 100 * RD_EPS) rtol = 100 * RD_EPS;
+    rd_ctx R = {p, &c, N, n, NULL, NULL, groups, 0, NULL, st};
+    if (!groups) {
+        R.own_groups = (int32_t *)malloc(sizeof(int32_t) * n);
+        for (int64_t j = 0; j < n; j++) R.own_groups[j] = (int32_t)(3 * (j / N) + (j % N) % 3);
+        R.groups = R.own_groups;
+    }
+    for (int64_t j = 0; j < n; j++)
+        if (R.groups[j] + 1 > R.n_groups) R.n_groups = R.groups[j] + 1;
+    /* bdf.py:246-249 */
+    const double kappa[6] = {0, -0.1850, -1.0 / 9, -0.0823, -0.0415, 0};
+    double gamma_[6], alpha[6], error_const[6];
+    gamma_[0] = 0;
+    for (int k = 1; k <= BDF_MAX_ORDER; k++) gamma_[k] = gamma_[k - 1] + 1.0 / k; /* np.cumsum */
+    for (int k = 0; k <= BDF_MAX_ORDER; k++) {
+        alpha[k] = (1 - kappa[k]) * gamma_[k];
+        error_const[k] = kappa[k] * gamma_[k] + 1.0 / (k + 1);
+    }
+
+    double *D = (double *)calloc((size_t)(BDF_MAX_ORDER + 3) * n, sizeof(double));
+    double *buf = (double *)malloc(sizeof(double) * (size_t)n * 10);
+    R.J = (double *)calloc((size_t)N * 75, sizeof(double));
+    double *ab = (double *)malloc(sizeof(double) * (size_t)(RD_LDAB * n));
+    int32_t *piv = (int32_t *)malloc(sizeof(int32_t) * n);
+    if (!D || !buf || !R.J || !ab || !piv) return -2;
+    double *f = buf, *ypred = buf + n, *scale = buf + 2 * n, *psi = buf + 3 * n, *ynew = buf + 4 * n, *d = buf + 5 * n, *rhs = buf + 6 * n,
+           *dy = buf + 7 * n, *scratch = buf + 8 * n, *f0 = buf + 9 * n;
+    double g[MARL_NEVENTS], g_new[MARL_NEVENTS];
+    int64_t steps_out = 0, eval_i = 0, attempts = 0;
+
+    /* BDF.__init__, bdf.py:197-258 */
+    double t = t0;
+    rd_fun(&R, y, f);
+    double S_h_abs = first_step;
+    const double newton_tol = fmax(10 * RD_EPS / rtol, fmin(0.03, sqrt(rtol)));
+    rd_fun_uncounted(&R, y, f0); /* jac_wrapped: f = self.fun_single(t, y) - not counted */
+    if (rd_num_jac(&R, y, f0, atol)) return -2;
+    memcpy(D, y, sizeof(double) * n);
+    for (int64_t i = 0; i < n; i++) D[n + i] = f[i] * S_h_abs;
+    int order = 1, n_equal_steps = 0, have_lu = 0;
+    orc_events(p, &c, N, y, g);
+    int status = 1;
+
+    while (status == 1) {
+        if (t == t1) { status = 0; break; }
+        /* ---- _step_impl, bdf.py:310-450 ---- */
+        const double min_step = 10 * fabs(nextafter(t, INFINITY) - t);
+        double h_abs;
+        if (S_h_abs < min_step) {
+            h_abs = min_step;
+            bdf_change_D(D, n, order, min_step / S_h_abs);
+            n_equal_steps = 0;
+        } else {
+            h_abs = S_h_abs;
+        }
+        int current_jac = 0; /* self.jac is a callable (the finite-difference wrapper) */
+        int accepted = 0, n_iter = 0;
+        double h = 0, t_new = t, error_norm = 0, safety = 0;
+        while (!accepted) {
+            if (h_abs < min_step) { status = -1; break; }
+            if (max_attempts > 0 && attempts >= max_attempts) { status = 2; break; }
+            attempts++;
+            h = h_abs;
+            t_new = t + h;
+            if (t_new - t1 > 0) {
+                t_new = t1;
+                bdf_change_D(D, n, order, fabs(t_new - t) / h_abs);
+                n_equal_steps = 0;
+                have_lu = 0;
+            }
+            h = t_new - t;
+            h_abs = fabs(h);
+            for (int64_t i = 0; i < n; i++) { /* np.sum(D[:order + 1], axis=0): rows added in order */
+                double a = D[i];
+                for (int j = 1; j <= order; j++) a += D[(int64_t)j * n + i];
+                ypred[i] = a;
+                scale[i] = atol + rtol * fabs(a);
+                double q = 0; /* np.dot(D[1:order + 1].T, gamma[1:order + 1]) / alpha[order] */
+                for (int j = 1; j <= order; j++) q += D[(int64_t)j * n + i] * gamma_[j];
+                psi[i] = q / alpha[order];
+            }
+            int converged = 0;
+            const double cc = h / alpha[order];
+            while (!converged) {
+                if (!have_lu) {
+                    bdf_assemble(&R, cc, ab);
+                    band_factor_d(n, ab, piv);
+                    st->nlu++;
+                    have_lu = 1;
+                }
+                /* ---- solve_bdf_system, bdf.py:36-68 ---- */
+                memset(d, 0, sizeof(double) * n);
+                memcpy(ynew, ypred, sizeof(double) * n);
+                double dy_norm_old = -1;
+                int k;
+                for (k = 0; k < BDF_NEWTON_MAXITER; k++) {
+                    rd_fun(&R, ynew, scratch);
+                    int finite = 1;
+                    for (int64_t i = 0; i < n && finite; i++)
+                        if (!isfinite(scratch[i])) finite = 0;
+                    if (!finite) break;
+                    for (int64_t kk = 0; kk < n; kk++) {
+                        const int64_t i = rd_perm(N, kk);
+                        rhs[kk] = (cc * scratch[i] - psi[i]) - d[i];
+                    }
+                    band_solve_d(n, ab, piv, rhs);
+                    for (int64_t kk = 0; kk < n; kk++) dy[rd_perm(N, kk)] = rhs[kk];
+                    const double dy_norm = bdf_norm(dy, 1.0, scale, n);
+                    double rate = -1;
+                    if (dy_norm_old >= 0) rate = dy_norm / dy_norm_old;
+                    if (rate >= 0 && (rate >= 1 || pow(rate, BDF_NEWTON_MAXITER - k) / (1 - rate) * dy_norm > newton_tol)) break;
+                    for (int64_t i = 0; i < n; i++) { ynew[i] += dy[i]; d[i] += dy[i]; }
+                    if (dy_norm == 0 || (rate >= 0 && rate / (1 - rate) * dy_norm < newton_tol)) { converged = 1; break; }
+                    dy_norm_old = dy_norm;
+                }
+                n_iter = (k < BDF_NEWTON_MAXITER ? k : BDF_NEWTON_MAXITER - 1) + 1;
+                if (!converged) {
+                    if (current_jac) break;
+                    rd_fun_uncounted(&R, ypred, f0); /* J = self.jac(t_new, y_predict) */
+                    if (rd_num_jac(&R, ypred, f0, atol)) return -2;
+                    have_lu = 0;
+                    current_jac = 1;
+                }
+            }
+            if (!converged) {
+                h_abs *= 0.5;
+                bdf_change_D(D, n, order, 0.5);
+                n_equal_steps = 0;
+                have_lu = 0;
+                st->n_rejected++;
+                continue;
+            }
+            safety = 0.9 * (2 * BDF_NEWTON_MAXITER + 1) / (2 * BDF_NEWTON_MAXITER + n_iter);
+            for (int64_t i = 0; i < n; i++) scale[i] = atol + rtol * fabs(ynew[i]);
+            error_norm = bdf_norm(d, error_const[order], scale, n);
+            if (error_norm > 1) {
+                const double sf = safety * pow(error_norm, -1.0 / (order + 1));
+                const double factor = (sf > RD_MIN_FACTOR) ? sf : RD_MIN_FACTOR;
+                h_abs *= factor;
+                bdf_change_D(D, n, order, factor);
+                n_equal_steps = 0;
+                st->n_rejected++;
+                /* (bdf.py:405-406: the LU is NOT reset here) */
+            } else {
+                accepted = 1;
+            }
+        }
+        if (status != 1) break;
+        n_equal_steps++;
+        const double t_old = t;
+        t = t_new;
+        memcpy(y, ynew, sizeof(double) * n);
+        S_h_abs = h_abs;
+        st->n_accepted++;
+        for (int64_t i = 0; i < n; i++) { /* bdf.py:419-422 */
+            D[(int64_t)(order + 2) * n + i] = d[i] - D[(int64_t)(order + 1) * n + i];
+            D[(int64_t)(order + 1) * n + i] = d[i];
+            for (int j = order; j >= 0; j--) D[(int64_t)j * n + i] += D[(int64_t)(j + 1) * n + i];
+        }
+        if (n_equal_steps >= order + 1) {
+            const double em = order > 1 ? bdf_norm(D + (int64_t)order * n, error_const[order - 1], scale, n) : INFINITY;
+            const double ep = order < BDF_MAX_ORDER ? bdf_norm(D + (int64_t)(order + 2) * n, error_const[order + 1], scale, n) : INFINITY;
+            const double en[3] = {em, error_norm, ep};
+            double factors[3];
+            int best = 0;
+            for (int i = 0; i < 3; i++) {
+                factors[i] = pow(en[i], -1.0 / (order + i)); /* inf -> 0, 0 -> inf (errstate ignore) */
+                if (factors[i] > factors[best]) best = i; /* np.argmax: the first maximum; NaN handling: see below */
+            }
+            for (int i = 0; i < 3; i++) /* np.argmax returns the first NaN if there is one */
+                if (factors[i] != factors[i]) { best = i; break; }
+            order += best - 1;
+            const double sf = safety * factors[best];
+            const double factor = (sf < RD_MAX_FACTOR) ? sf : RD_MAX_FACTOR; /* min(MAX_FACTOR, x): NaN stays NaN in python... */
+            S_h_abs *= (sf != sf) ? sf : factor;
+            bdf_change_D(D, n, order, (sf != sf) ? sf : factor);
+            n_equal_steps = 0;
+            have_lu = 0;
+        }
+        if (t - t1 >= 0) status = 0;
+        if (step_times && steps_out < max_steps_out) step_times[steps_out] = t;
+        steps_out++;
+
+        /* _dense_output_impl (bdf.py:452-454): built AFTER the order / step-size update, from self.h_abs, self.order, self.D */
+        orc_dense dense = {p, &c, N, t, S_h_abs, NULL, NULL, scratch, NULL, D, order};
+        orc_events(p, &c, N, y, g_new);
+        for (int e = 0; e < MARL_NEVENTS; e++) {
+            const int up = (g[e] <= 0) && (g_new[e] >= 0), down = (g[e] >= 0) && (g_new[e] <= 0);
+            if (up || down) {
+                if (t_events && st->n_events[e] < max_events)
+                    t_events[e * max_events + st->n_events[e]] = orc_brent(&dense, e, t_old, t);
+                st->n_events[e]++;
+            }
+            g[e] = g_new[e];
+        }
+        while (t_eval && eval_i < n_eval && t_eval[eval_i] <= t) {
+            orc_dense_eval(&dense, t_eval[eval_i], y_eval + eval_i * n);
+            eval_i++;
+        }
+    }
+    st->status = status;
+    st->t = t;
+    st->h_next = S_h_abs;
+    orc_events(p, &c, N, y, st->event_value);
+    if (n_steps_out) *n_steps_out = steps_out;
+    free(D); free(buf); free(R.J); free(R.factor); free(R.own_groups); free(ab); free(piv);
     return status;
 }

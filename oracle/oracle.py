@@ -39,6 +39,8 @@ def lib(omp=False):
         L.marl_oracle_radau.argtypes = [P, I64, VP, D, D, D, D, D, VP, VP, I64, VP, VP, I64, C.POINTER(I64), VP, I64, I64,
                                         C.POINTER(MarlStats)]
         L.marl_oracle_radau.restype = C.c_int
+        L.marl_oracle_bdf.argtypes = L.marl_oracle_radau.argtypes
+        L.marl_oracle_bdf.restype = C.c_int
         L.marl_oracle_rk4_batch.argtypes = [P, I64, I64, VP, VP, I64]
         L.marl_oracle_rk4_batch.restype = C.c_int
         _libs[name] = L
@@ -146,10 +148,19 @@ def scipy_groups(N):
     return np.ascontiguousarray(group_columns(csc_matrix(pat)), dtype=np.int32)
 
 
+def bdf(P, N, y0, t0, t1, first_step, rtol, atol, groups=None, t_eval=None, max_steps_out=1 << 20, max_events=4096, max_attempts=0):
+    """scipy solve_ivp(method="BDF", jac_sparsity=...) restated (same conventions as radau below)."""
+    return _implicit("marl_oracle_bdf", P, N, y0, t0, t1, first_step, rtol, atol, groups, t_eval, max_steps_out, max_events, max_attempts)
+
+
 def radau(P, N, y0, t0, t1, first_step, rtol, atol, groups=None, t_eval=None, max_steps_out=1 << 20, max_events=4096,
           max_attempts=0):
     """scipy solve_ivp(method="Radau", jac_sparsity=...) restated.  Returns (y_final, stats, step_times, y_eval, t_events);
     stats.njev / stats.nlu as scipy counts them."""
+    return _implicit("marl_oracle_radau", P, N, y0, t0, t1, first_step, rtol, atol, groups, t_eval, max_steps_out, max_events, max_attempts)
+
+
+def _implicit(entry, P, N, y0, t0, t1, first_step, rtol, atol, groups, t_eval, max_steps_out, max_events, max_attempts):
     y = np.array(y0, dtype=np.float64)
     st = MarlStats()
     te = None if t_eval is None else np.ascontiguousarray(t_eval, dtype=np.float64)
@@ -159,7 +170,7 @@ def radau(P, N, y0, t0, t1, first_step, rtol, atol, groups=None, t_eval=None, ma
     nsteps = C.c_int64(0)
     tev = np.full((NEVENTS, max_events), np.nan)
     g = None if groups is None else np.ascontiguousarray(groups, dtype=np.int32)
-    lib().marl_oracle_radau(C.byref(P), N, _ptr(y), t0, t1, first_step, rtol, atol, _ptr(g) if g is not None else None,
+    getattr(lib(), entry)(C.byref(P), N, _ptr(y), t0, t1, first_step, rtol, atol, _ptr(g) if g is not None else None,
                             _ptr(te) if n_eval else None, n_eval, _ptr(y_eval), _ptr(steps), max_steps_out,
                             C.byref(nsteps), _ptr(tev), max_events, max_attempts, C.byref(st))
     t_events = [tev[e, :min(int(st.n_events[e]), max_events)].copy() for e in range(NEVENTS)]

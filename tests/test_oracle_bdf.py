@@ -1,0 +1,60 @@
+"""The oracle's restatement of scipy's BDF - the other implicit method the reference's Solver names for its jac_sparsity
+(marlpde/parameters.py:205-219) - pinned against scipy itself driving the REFERENCE's RHS with the reference's 27-diagonal
+jac_sparsity (goldens bdf_traj_*.npz, oracle/make_goldens.py gen_bdf).  No GPU needed.
+
+As for Radau (tests/test_oracle_radau.py): scipy factorises I - c J with SuperLU, the oracle with banded partial-pivoting LU, so
+states agree to rounding amplified by the finite-difference Jacobian (~1e-8), not to the last bit; every decision - accept / reject,
+Jacobian refresh, refactorisation, order change - is the same on these runs: nfev, njev, nlu and the step count are EQUAL."""
+import json
+
+import numpy as np
+import pytest
+
+from common import GOLDEN
+
+
+def _run(oracle, name, groups="scipy"):
+    from dataclasses import asdict
+    from marlpde_amd.parameters import Map_Scenario
+    g = np.load(f"{GOLDEN}/bdf_traj_{name}.npz")
+    N = int(g["N"])
+    p = asdict(Map_Scenario()) | json.loads(str(g["overrides"])) | {"N": N}
+    out = oracle.bdf(oracle.params_from_dict(p), N, g["y0"], *g["t_span"], float(g["first_step"]), float(g["rtol"]), float(g["atol"]),
+                     groups=oracle.scipy_groups(N) if groups == "scipy" else None, t_eval=g["t_span"])
+    return g, out
+
+
+@pytest.mark.parametrize("name", ["A", "matlab", "A_N64_tight"])
+def test_bdf_walks_scipys_sequence(oracle, name):
+    g, (y, st, steps, ye, tev) = _run(oracle, name)
+    assert st.status == 0 == int(g["status"])
+    assert (st.nfev, st.njev, st.nlu) == (int(g["nfev"]), int(g["njev"]), int(g["nlu"]))
+    ts = g["step_times"][1:]
+    assert len(steps) == len(ts) and np.max(np.abs(steps - ts) / ts) <= 1e-5
+    assert np.max(np.abs(y - g["y_final"])) <= 1e-6
+    # (the sample at t0 comes from the first step's dense output, a polynomial through the differences: y0 up to rounding)
+    assert np.max(np.abs(ye[-1] - g["y_final"])) <= 1e-6 and np.max(np.abs(ye[0] - g["y0"])) <= 1e-9
+    assert [len(e) for e in tev] == list(g["n_events"])
+    if sum(g["n_events"]):   # Scenario A: min(CA) grazes zero with slope ~2e-4 per unit time (see tests/test_oracle_radau.py)
+        assert np.max(np.abs(np.concatenate(tev) - g["t_events"])) <= 5e-4
+
+
+def test_bdf_grouping_does_not_change_the_run(oracle):
+    g, a = _run(oracle, "A")
+    _, b = _run(oracle, "A", groups=None)
+    assert (a[1].nfev, a[1].njev, a[1].nlu) == (b[1].nfev, b[1].njev, b[1].nlu)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("name,gold_file", [("A", "ref_final_scenarioA_Phi0_0.6_PhiIni_0.5.npy"), ("matlab", "ref_matlab_Phi_0.5_k3_k4_0.01.npy")])
+def test_bdf_against_the_reference_regression_data(oracle, name, gold_file):
+    """Another integrator, the same physics: the BDF end states within the reference's tolerances of its HDF5 regression data
+    (tests/Regression_test/test_regression.py:29-30, 136-148)."""
+    g, (y, st, *_rest) = _run(oracle, name)
+    last, gold = y.reshape(5, 200), np.load(f"{GOLDEN}/{gold_file}")
+    if name == "matlab":
+        xs = (np.arange(200) + 0.5) * (500.0 / 200)
+        interp = np.stack([np.interp(xs, np.linspace(0, 500, 201), gold[f]) for f in range(5)])
+        np.testing.assert_allclose(last[:, 2:], interp[:, 2:], atol=0.05)
+    else:
+        np.testing.assert_allclose(last, gold, rtol=0.1, atol=0.01)
