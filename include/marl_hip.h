@@ -128,6 +128,13 @@ int marl_sweep_rk45_dev(marl_ctx* ctx, double* y_dev, double t0, double t1, doub
 int marl_integrate_radau(marl_ctx* ctx, double* y, double t0, double t1, double first_step, double rtol, double atol,
                          const int32_t* groups, const double* t_eval, int64_t n_eval, double* y_eval, double* t_events,
                          int64_t max_events, int64_t max_attempts, marl_stats* stats);
+/* The same with scipy's BDF (scipy/integrate/_ivp/bdf.py: variable order 1..5, quasi-constant step NDF) - the other implicit method
+ * the reference's Solver names for its jac_sparsity (marlpde/parameters.py:205-219); replaces
+ * solve_ivp(fun, method="BDF", jac_sparsity=...) at marlpde/Evolve_scenario.py:104-109.  The matrix factorised is I - c J (one real
+ * block-tridiagonal system per step size / order change, by cyclic reduction); arguments and statistics as for marl_integrate_radau. */
+int marl_integrate_bdf(marl_ctx* ctx, double* y, double t0, double t1, double first_step, double rtol, double atol,
+                         const int32_t* groups, const double* t_eval, int64_t n_eval, double* y_eval, double* t_events,
+                         int64_t max_events, int64_t max_attempts, marl_stats* stats);
 
 /* A SWEEP of Radau integrations (the reference integrates one scenario per process with this solver; its tests loop over
  * scenarios: tests/Regression_test/test_regression.py:44,74,115-116): every instance of the context with its own parameters, step-size

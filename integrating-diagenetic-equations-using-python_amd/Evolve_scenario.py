@@ -66,7 +66,7 @@ def integrate_equations(solver_parms, tracker_parms, pde_parms, results_root="..
         if status not in (0, -1):
             status = -1
         covered = Tstar * (t_span[1] if status == 0 else res.t_reached)
-    elif method == "Radau" and not solver_parms.get("scipy_driver", False):
+    elif method in ("Radau", "BDF") and not solver_parms.get("scipy_driver", False):
         # the reference's default: the whole implicit loop on the GPU (marl_integrate_radau).  The Jacobian pattern is the
         # reference's (parameters.py:150-199); when the caller's jac_sparsity has the matching shape its scipy column grouping
         # is used, otherwise a structured colouring - the Jacobian entries are the same either way.
@@ -76,8 +76,8 @@ def integrate_equations(solver_parms, tracker_parms, pde_parms, results_root="..
             from scipy.optimize._numdiff import group_columns
             from scipy.sparse import csc_matrix
             groups = group_columns(csc_matrix(sp))
-        res = eq.integrate_radau(y0, t_span, solver_parms["first_step"], solver_parms["rtol"], solver_parms["atol"], t_eval=t_eval,
-                                 groups=groups)
+        integrate = eq.integrate_radau if method == "Radau" else eq.integrate_bdf   # (marl_integrate_bdf: the same machinery, scipy's BDF step logic)
+        res = integrate(y0, t_span, solver_parms["first_step"], solver_parms["rtol"], solver_parms["atol"], t_eval=t_eval, groups=groups)
         t_out, y_out, t_events = res.t, res.y, res.t_events
         nfev, njev, nlu, status, message = res.nfev, res.njev, res.nlu, res.status, res.message
         if status not in (0, -1):

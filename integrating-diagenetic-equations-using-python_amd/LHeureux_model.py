@@ -307,6 +307,15 @@ class LMAHeureuxPorosityDiff:
 
         ``groups``: scipy's column grouping of the pattern (``scipy.optimize._numdiff.group_columns``), or None for a
         structured 15-colouring (same Jacobian).  Returns an :class:`RK45Result` (``nfev``/``njev``/``nlu`` as scipy counts)."""
+        return self._integrate_implicit("marl_integrate_radau", y0, t_span, first_step, rtol, atol, t_eval, events, max_events, max_attempts, groups)
+
+    def integrate_bdf(self, y0, t_span, first_step, rtol, atol, t_eval=None, events=True, max_events=4096, max_attempts=0, groups=None):
+        """scipy ``solve_ivp(method="BDF", jac_sparsity=<the reference's pattern>)`` semantics for ONE instance - the other implicit
+        method the reference's Solver names (marlpde/parameters.py:205-219) - on the device (marl_integrate_bdf): variable order 1..5,
+        the matrix I - c J factorised by cyclic reduction.  Arguments and result as for :meth:`integrate_radau`."""
+        return self._integrate_implicit("marl_integrate_bdf", y0, t_span, first_step, rtol, atol, t_eval, events, max_events, max_attempts, groups)
+
+    def _integrate_implicit(self, entry, y0, t_span, first_step, rtol, atol, t_eval, events, max_events, max_attempts, groups):
         y_start = self._host_state(y0)
         n = y_start.size
         te = None if t_eval is None else np.ascontiguousarray(t_eval, dtype=np.float64)
@@ -319,11 +328,11 @@ class LMAHeureuxPorosityDiff:
             stats = MarlStats()
             y_eval = np.empty((max(n_eval, 1), n))
             tev = np.full((NEVENTS, max_events), np.nan) if events else None
-            rc = self._lib.marl_integrate_radau(
+            rc = getattr(self._lib, entry)(
                 self._ctx, _as_ptr(y), float(t_span[0]), float(t_span[1]), float(first_step), float(rtol), float(atol),
                 _as_ptr(grp) if grp is not None else None, _as_ptr(te) if n_eval else None, n_eval, _as_ptr(y_eval) if n_eval else None,
                 _as_ptr(tev) if events else None, max_events if events else 0, int(max_attempts), C.byref(stats))
-            self._check(rc, "marl_integrate_radau")
+            self._check(rc, entry)
             most = max(stats.n_events[:]) if events else 0
             if most <= max_events:
                 break

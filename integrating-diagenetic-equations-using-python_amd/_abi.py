@@ -66,6 +66,7 @@ PROTOTYPES = {
     "marl_integrate_rk45_dev": (_I, [_P, _P, _I, _D, _D, _D, _D, _D, _L, C.POINTER(MarlStats)]),
     "marl_sweep_rk45_dev": (_I, [_P, _P, _D, _D, _D, _D, _D, _L, C.POINTER(MarlStats)]),
     "marl_integrate_radau": (_I, [_P, _P, _D, _D, _D, _D, _D, _P, _P, _L, _P, _P, _L, _L, C.POINTER(MarlStats)]),
+    "marl_integrate_bdf": (_I, [_P, _P, _D, _D, _D, _D, _D, _P, _P, _L, _P, _P, _L, _L, C.POINTER(MarlStats)]),
     "marl_sweep_radau_dev": (_I, [_P, _P, _D, _D, _D, _D, _D, _P, _L, C.POINTER(MarlStats)]),
     "marl_ctx_create_slab": (_I, [C.POINTER(MarlParams), _L, _L, _L, _L, _I, C.POINTER(_P)]),
     "marl_slab_load": (_I, [_P, _P]),

@@ -16,6 +16,7 @@
 #include "marl_kernels.h"
 #include "marl_radau.h"
 #include "marl_radau_batch.h"
+#include "marl_bdf.h"
 
 using namespace marl;
 
@@ -1776,6 +1777,320 @@ int radau_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_st
     if (int rc = radau_monitors(ctx, w.y, st->event_value)) return rc;
     return 0;
 }
+
+// ---- BDF (scipy/integrate/_ivp/bdf.py), the other implicit method the reference's Solver names --------------------------------------
+// compute_R / change_D (bdf.py:18-33): D[:order + 1] = (R U)^T D[:order + 1]
+void bdf_compute_R(int order, double factor, double R[6][6])
+{
+    for (int j = 0; j <= order; j++) R[0][j] = 1;
+    for (int i = 1; i <= order; i++) {
+        R[i][0] = 0;
+        for (int j = 1; j <= order; j++) R[i][j] = R[i - 1][j] * ((i - 1 - factor * j) / i);
+    }
+}
+
+int bdf_change_D(marl_ctx* ctx, double* D, int64_t n, int order, double factor)
+{
+    double R[6][6], U[6][6];
+    bdf::Mat6 RU = {};
+    bdf_compute_R(order, factor, R);
+    bdf_compute_R(order, 1.0, U);
+    for (int i = 0; i <= order; i++)
+        for (int j = 0; j <= order; j++) {
+            double a = 0;
+            for (int k = 0; k <= order; k++) a += R[i][k] * U[k][j];
+            RU.m[i][j] = a;
+        }
+    hipLaunchKernelGGL(bdf::change_D_kernel, dim3(blocks256(n)), dim3(256), 0, ctx->stream, D, n, order, RU);
+    LAUNCH_OK(ctx);
+    return 0;
+}
+
+// sum (coef v / (atol + rtol |yref|))^2 -> host
+int bdf_scaled_sumsq(marl_ctx* ctx, RadauWork& w, const double* v, double coef, const double* yref, double rtol, double atol, double* ss)
+{
+    const int64_t n = NF * ctx->N;
+    const int nbk = radau_norm_blocks(n);
+    hipLaunchKernelGGL(bdf::scaled_norm_kernel, dim3(nbk), dim3(1024), 0, ctx->stream, v, coef, yref, rtol, atol, n, nbk > 1 ? w.partial : w.out);
+    LAUNCH_OK(ctx);
+    if (nbk > 1) {
+        hipLaunchKernelGGL(radau::sum_partials_kernel, dim3(1), dim3(1), 0, ctx->stream, w.partial, nbk, w.out);
+        LAUNCH_OK(ctx);
+    }
+    return radau_read(ctx, w, ss, nullptr);
+}
+
+struct BdfDense { double t, h; int order; const double* D; };
+
+int bdf_dense(marl_ctx* ctx, const BdfDense& d, double tq, double* out)
+{
+    bdf::Vec6 p = {};
+    double acc = 1;
+    for (int j = 0; j < d.order; j++) {   // x_j = (t - (t_end - h j)) / (h (1 + j)); p = cumprod(x)
+        acc *= (tq - (d.t - d.h * j)) / (d.h * (1 + j));
+        p.v[j] = acc;
+    }
+    const int64_t n = NF * ctx->N;
+    hipLaunchKernelGGL(bdf::dense_kernel, dim3(blocks256(n)), dim3(256), 0, ctx->stream, d.D, n, d.order, p, out);
+    LAUNCH_OK(ctx);
+    return 0;
+}
+
+// Brent on monitor e over the BDF dense output (as radau_brent)
+int bdf_brent(marl_ctx* ctx, RadauWork& w, const BdfDense& d, int e, double a, double b, double* root)
+{
+    const double xtol = 4 * 2.220446049250313e-16, rtol = xtol;
+    double g[7];
+    auto at = [&](double t, double* v) -> int {
+        if (int rc = bdf_dense(ctx, d, t, w.tmp)) return rc;
+        if (int rc = radau_monitors(ctx, w.tmp, g)) return rc;
+        *v = g[e];
+        return 0;
+    };
+    double fa, fb;
+    if (int rc = at(a, &fa)) return rc;
+    if (int rc = at(b, &fb)) return rc;
+    if (fa == 0) { *root = a; return 0; }
+    if (fb == 0) { *root = b; return 0; }
+    double xpre = a, xcur = b, fpre = fa, fcur = fb, xblk = 0, fblk = 0, spre = 0, scur = 0;
+    for (int it = 0; it < 100; it++) {
+        if (fpre != 0 && fcur != 0 && ((fpre < 0) != (fcur < 0))) { xblk = xpre; fblk = fpre; spre = scur = xcur - xpre; }
+        if (std::fabs(fblk) < std::fabs(fcur)) { xpre = xcur; xcur = xblk; xblk = xpre; fpre = fcur; fcur = fblk; fblk = fpre; }
+        const double delta = (xtol + rtol * std::fabs(xcur)) / 2, sbis = (xblk - xcur) / 2;
+        if (fcur == 0 || std::fabs(sbis) < delta) break;
+        if (std::fabs(spre) > delta && std::fabs(fcur) < std::fabs(fpre)) {
+            double stry;
+            if (xpre == xblk) stry = -fcur * (xcur - xpre) / (fcur - fpre);
+            else {
+                const double dpre = (fpre - fcur) / (xpre - xcur), dblk = (fblk - fcur) / (xblk - xcur);
+                stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
+            }
+            if (2 * std::fabs(stry) < std::fmin(std::fabs(spre), 3 * std::fabs(sbis) - delta)) { spre = scur; scur = stry; }
+            else { spre = sbis; scur = sbis; }
+        } else { spre = sbis; scur = sbis; }
+        xpre = xcur; fpre = fcur;
+        if (std::fabs(scur) > delta) xcur += scur; else xcur += (sbis > 0 ? delta : -delta);
+        if (int rc = at(xcur, &fcur)) return rc;
+    }
+    *root = xcur;
+    return 0;
+}
+
+// BDF.__init__ + the solve_ivp loop (ivp.py:654-723) around BDF._step_impl (bdf.py:310-450).  Buffers of the Radau arena are reused:
+// D = [Z | W | F] (8 n of 9 n), f = Z0, y_predict / psi / d = Q.
+int bdf_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_step, double rtol, double atol, const double* t_eval,
+            int64_t n_eval, double* y_eval_host, double* t_events, int64_t max_events, int64_t max_attempts, marl_stats* st)
+{
+    const int64_t N = ctx->N, n = NF * N;
+    constexpr int NEWTON_MAXITER = 4, MAX_ORDER = 5;
+    constexpr double MIN_FACTOR = 0.2, MAX_FACTOR = 10;
+    memset(st, 0, sizeof *st);
+    rtol = clamp_rtol(rtol);
+    const dim3 gn(blocks256(n)), b256(256);
+    const double kappa[6] = {0, -0.1850, -1.0 / 9, -0.0823, -0.0415, 0};
+    bdf::Vec6 gamma = {};
+    double alpha[6], error_const[6];
+    for (int k = 1; k <= MAX_ORDER; k++) gamma.v[k] = gamma.v[k - 1] + 1.0 / k;
+    for (int k = 0; k <= MAX_ORDER; k++) { alpha[k] = (1 - kappa[k]) * gamma.v[k]; error_const[k] = kappa[k] * gamma.v[k] + 1.0 / (k + 1); }
+    double* D = w.Z;            // [MAX_ORDER + 3][n]
+    double* f = w.Z0;           // f(t_new, y) of the Newton iteration
+    double* ypred = w.Q, *psi = w.Q + n, *d = w.Q + 2 * n;
+    w.pcr = true;               // (the sequential block-Thomas option serves the Radau path only)
+
+    double t = t0;
+    if (int rc = launch_rhs(ctx, w.y, w.f, LAYOUT_FIELD_MAJOR)) return rc;
+    st->nfev = 1;
+    double S_h_abs = first_step;
+    const double newton_tol = std::fmax(10 * radau::EPS / rtol, std::fmin(0.03, std::sqrt(rtol)));
+    HIP_OK(ctx, hipMemsetAsync(w.flags, 0, sizeof(int32_t) * 2, ctx->stream));
+    // jac_wrapped(t0, y0): f = fun_single(t, y) (not counted; the same values as w.f), J by finite differences
+    if (int rc = radau_num_jac(ctx, w, w.y, w.f, atol)) return rc;
+    st->njev = 1;
+    hipLaunchKernelGGL(bdf::init_D_kernel, gn, b256, 0, ctx->stream, w.y, w.f, S_h_abs, n, D);
+    LAUNCH_OK(ctx);
+    int order = 1, n_equal_steps = 0;
+    bool have_lu = false;
+    double g[7], g_new[7];
+    if (int rc = radau_monitors(ctx, w.y, g)) return rc;
+    int64_t eval_i = 0, attempts = 0;
+    int status = 1;
+
+    while (status == 1) {
+        if (t == t1) { status = 0; break; }
+        const double min_step = 10 * std::fabs(std::nextafter(t, INFINITY) - t);
+        double h_abs;
+        if (S_h_abs < min_step) {
+            h_abs = min_step;
+            if (int rc = bdf_change_D(ctx, D, n, order, min_step / S_h_abs)) return rc;
+            n_equal_steps = 0;
+        } else {
+            h_abs = S_h_abs;
+        }
+        bool current_jac = false, accepted = false;
+        int n_iter = 0;
+        double h = 0, t_new = t, error_norm = 0, safety = 0;
+        while (!accepted) {
+            if (h_abs < min_step) { status = -1; break; }
+            if (max_attempts > 0 && attempts >= max_attempts) { status = 2; break; }
+            attempts++;
+            h = h_abs;
+            t_new = t + h;
+            if (t_new - t1 > 0) {
+                t_new = t1;
+                if (int rc = bdf_change_D(ctx, D, n, order, std::fabs(t_new - t) / h_abs)) return rc;
+                n_equal_steps = 0;
+                have_lu = false;
+            }
+            h = t_new - t;
+            h_abs = std::fabs(h);
+            hipLaunchKernelGGL(bdf::predict_kernel, gn, b256, 0, ctx->stream, D, n, order, gamma, alpha[order], rtol, atol, ypred, w.scale, psi, w.ynew, d);
+            LAUNCH_OK(ctx);
+            bool converged = false;
+            const double c = h / alpha[order];
+            bool first_pass = true;
+            while (!converged) {
+                if (!have_lu) {   // LU = self.lu(self.I - c * J)
+                    for (int level = -1; level < w.nlevels; level++) {
+                        hipLaunchKernelGGL(radau::pcr_factor_kernel, dim3((unsigned)((N + radau::PCR_CELLS_PER_BLOCK - 1) / radau::PCR_CELLS_PER_BLOCK), 1), dim3(256),
+                                           0, ctx->stream, w.J, N, level, 1.0, cplx{0, 0}, w.Sr, w.Sc, ZBatch{0, nullptr, 0, 0, nullptr}, c);
+                        LAUNCH_OK(ctx);
+                    }
+                    st->nlu++;
+                    have_lu = true;
+                }
+                if (!first_pass) {
+                    hipLaunchKernelGGL(bdf::newton_restart_kernel, gn, b256, 0, ctx->stream, ypred, n, w.ynew, d);
+                    LAUNCH_OK(ctx);
+                }
+                first_pass = false;
+                // ---- solve_bdf_system (bdf.py:36-68) ----
+                double dy_norm_old = -1;
+                int k;
+                for (k = 0; k < NEWTON_MAXITER; k++) {
+                    if (int rc = launch_rhs(ctx, w.ynew, f, LAYOUT_FIELD_MAJOR)) return rc;
+                    st->nfev++;
+                    hipLaunchKernelGGL(bdf::newton_rhs_kernel, gn, b256, 0, ctx->stream, f, psi, d, N, c, w.rhs_r, w.flags);
+                    LAUNCH_OK(ctx);
+                    if (int rc = radau_solve(ctx, w, false)) return rc;
+                    {
+                        const int nbk = radau_norm_blocks(n);
+                        hipLaunchKernelGGL(bdf::newton_update_kernel, dim3(nbk), dim3(1024), 0, ctx->stream, w.rhs_r, w.scale, N, w.ynew, d, nbk > 1 ? w.partial : w.out);
+                        LAUNCH_OK(ctx);
+                        if (nbk > 1) {
+                            hipLaunchKernelGGL(radau::sum_partials_kernel, dim3(1), dim3(1), 0, ctx->stream, w.partial, nbk, w.out);
+                            LAUNCH_OK(ctx);
+                        }
+                    }
+                    double ss;
+                    int nonfinite;
+                    if (int rc = radau_read(ctx, w, &ss, &nonfinite)) return rc;
+                    if (nonfinite) break;
+                    const double dy_norm = std::sqrt(ss) / std::sqrt((double)n);
+                    double rate = -1;
+                    if (dy_norm_old >= 0) rate = dy_norm / dy_norm_old;
+                    if (rate >= 0 && (rate >= 1 || std::pow(rate, NEWTON_MAXITER - k) / (1 - rate) * dy_norm > newton_tol)) break;
+                    if (dy_norm == 0 || (rate >= 0 && rate / (1 - rate) * dy_norm < newton_tol)) { converged = true; break; }
+                    dy_norm_old = dy_norm;
+                }
+                n_iter = (k < NEWTON_MAXITER ? k : NEWTON_MAXITER - 1) + 1;
+                if (!converged) {
+                    if (current_jac) break;
+                    // J = self.jac(t_new, y_predict): f = fun_single(t_new, y_predict) - not counted
+                    if (int rc = launch_rhs(ctx, ypred, w.fnew, LAYOUT_FIELD_MAJOR)) return rc;
+                    if (int rc = radau_num_jac(ctx, w, ypred, w.fnew, atol)) return rc;
+                    st->njev++;
+                    have_lu = false;
+                    current_jac = true;
+                }
+            }
+            if (!converged) {
+                h_abs *= 0.5;
+                if (int rc = bdf_change_D(ctx, D, n, order, 0.5)) return rc;
+                n_equal_steps = 0;
+                have_lu = false;
+                st->n_rejected++;
+                continue;
+            }
+            safety = 0.9 * (2 * NEWTON_MAXITER + 1) / (2 * NEWTON_MAXITER + n_iter);
+            double ss;
+            if (int rc = bdf_scaled_sumsq(ctx, w, d, error_const[order], w.ynew, rtol, atol, &ss)) return rc;
+            error_norm = std::sqrt(ss) / std::sqrt((double)n);
+            if (error_norm > 1) {
+                const double sf = safety * std::pow(error_norm, -1.0 / (order + 1));
+                const double factor = (sf > MIN_FACTOR) ? sf : MIN_FACTOR;
+                h_abs *= factor;
+                if (int rc = bdf_change_D(ctx, D, n, order, factor)) return rc;
+                n_equal_steps = 0;
+                st->n_rejected++;   // (bdf.py:405-406: the LU is kept)
+            } else {
+                accepted = true;
+            }
+        }
+        if (status != 1) break;
+        n_equal_steps++;
+        const double t_old = t;
+        t = t_new;
+        S_h_abs = h_abs;
+        st->n_accepted++;
+        hipLaunchKernelGGL(bdf::accept_kernel, gn, b256, 0, ctx->stream, D, d, w.ynew, n, order, w.y);
+        LAUNCH_OK(ctx);
+        if (n_equal_steps >= order + 1) {   // order / step-size selection (bdf.py:427-448); scale = atol + rtol |y_new| = |y| now
+            double em = INFINITY, ep = INFINITY, ss;
+            if (order > 1) {
+                if (int rc = bdf_scaled_sumsq(ctx, w, D + (int64_t)order * n, error_const[order - 1], w.y, rtol, atol, &ss)) return rc;
+                em = std::sqrt(ss) / std::sqrt((double)n);
+            }
+            if (order < MAX_ORDER) {
+                if (int rc = bdf_scaled_sumsq(ctx, w, D + (int64_t)(order + 2) * n, error_const[order + 1], w.y, rtol, atol, &ss)) return rc;
+                ep = std::sqrt(ss) / std::sqrt((double)n);
+            }
+            const double en[3] = {em, error_norm, ep};
+            double factors[3];
+            int best = 0;
+            for (int i = 0; i < 3; i++) {
+                factors[i] = std::pow(en[i], -1.0 / (order + i));
+                if (factors[i] > factors[best]) best = i;
+            }
+            for (int i = 0; i < 3; i++)
+                if (factors[i] != factors[i]) { best = i; break; }   // np.argmax: the first NaN
+            order += best - 1;
+            const double sf = safety * factors[best];
+            const double factor = (sf != sf) ? sf : ((sf < MAX_FACTOR) ? sf : MAX_FACTOR);
+            S_h_abs *= factor;
+            if (int rc = bdf_change_D(ctx, D, n, order, factor)) return rc;
+            n_equal_steps = 0;
+            have_lu = false;
+        }
+        if (t - t1 >= 0) status = 0;
+
+        // events and t_eval on the dense output built AFTER the order / step-size update (bdf.py:452-454)
+        const BdfDense dense = {t, S_h_abs, order, D};
+        if (int rc = radau_monitors(ctx, w.y, g_new)) return rc;
+        for (int e = 0; e < 7; e++) {
+            const bool up = g[e] <= 0 && g_new[e] >= 0, down = g[e] >= 0 && g_new[e] <= 0;
+            if (up || down) {
+                if (t_events && st->n_events[e] < max_events) {
+                    double root;
+                    if (int rc = bdf_brent(ctx, w, dense, e, t_old, t, &root)) return rc;
+                    t_events[e * max_events + st->n_events[e]] = root;
+                }
+                st->n_events[e]++;
+            }
+            g[e] = g_new[e];
+        }
+        while (t_eval && eval_i < n_eval && t_eval[eval_i] <= t) {
+            if (int rc = bdf_dense(ctx, dense, t_eval[eval_i], w.tmp)) return rc;
+            HIP_OK(ctx, hipMemcpyAsync(y_eval_host + eval_i * n, w.tmp, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+            eval_i++;
+        }
+    }
+    st->status = status;
+    st->t = t;
+    st->h_next = S_h_abs;
+    if (int rc = radau_monitors(ctx, w.y, st->event_value)) return rc;
+    return 0;
+}
 }  // namespace
 
 extern "C" int marl_integrate_radau(marl_ctx* ctx, double* y, double t0, double t1, double first_step, double rtol, double atol,
@@ -1796,6 +2111,29 @@ extern "C" int marl_integrate_radau(marl_ctx* ctx, double* y, double t0, double 
     const size_t n = (size_t)NF * ctx->N;
     HIP_OK(ctx, hipMemcpyAsync(w.y, y, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     if (int rc = radau_run(ctx, w, t0, t1, first_step, rtol, atol, t_eval, n_eval, y_eval, t_events, max_events, max_attempts, stats)) return rc;
+    HIP_OK(ctx, hipMemcpyAsync(y, w.y, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int marl_integrate_bdf(marl_ctx* ctx, double* y, double t0, double t1, double first_step, double rtol, double atol, const int32_t* groups,
+                                  const double* t_eval, int64_t n_eval, double* y_eval, double* t_events, int64_t max_events, int64_t max_attempts,
+                                  marl_stats* stats)
+{
+    if (!ctx || !y || !stats || (n_eval > 0 && (!t_eval || !y_eval))) return ctx ? fail(ctx, -1, "marl_integrate_bdf: invalid argument") : -1;
+    if (ctx->batch != 1 || ctx->halo > 0) return fail(ctx, -1, "marl_integrate_bdf: single-instance, whole-grid context required");
+    if (!(first_step > 0) || !(t1 >= t0)) return fail(ctx, -1, "bdf: need first_step > 0 and t1 >= t0 (forward integration)");
+    if (t1 > t0 && first_step > t1 - t0) return fail(ctx, -1, "bdf: `first_step` exceeds bounds");   // common.py:10-16
+    if (!(rtol > 0) || !(atol >= 0)) return fail(ctx, -1, "bdf: tolerances must be positive");
+    for (int64_t i = 0; i < n_eval; i++)
+        if (t_eval[i] < t0 || t_eval[i] > t1 || (i > 0 && t_eval[i] <= t_eval[i - 1]))
+            return fail(ctx, -1, "bdf: `t_eval` must be sorted and within t_span");
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    RadauWork w;
+    if (int rc = radau_alloc(ctx, w, groups)) return rc;
+    const size_t n = (size_t)NF * ctx->N;
+    HIP_OK(ctx, hipMemcpyAsync(w.y, y, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = bdf_run(ctx, w, t0, t1, first_step, rtol, atol, t_eval, n_eval, y_eval, t_events, max_events, max_attempts, stats)) return rc;
     HIP_OK(ctx, hipMemcpyAsync(y, w.y, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;

@@ -1,0 +1,162 @@
+// marl_bdf.h - vector kernels of the implicit BDF path (scipy/integrate/_ivp/bdf.py; the other method the reference's Solver names for
+// its jac_sparsity, marlpde/parameters.py:205-219).  The finite-difference Jacobian, the block-tridiagonal factorisation / solves of
+// I - c J (cyclic reduction, marl_radau.h) and the RHS are shared with the Radau path; the step logic runs on the host (marl_api.hip,
+// bdf_run) like marl_integrate_radau's.  State vectors are field-major (the reference's layout), linear systems cell-major.
+#pragma once
+#include "marl_radau.h"
+
+namespace marl {
+namespace bdf {
+
+constexpr int MAX_ORDER = 5;
+struct Mat6 { double m[MAX_ORDER + 1][MAX_ORDER + 1]; };
+struct Vec6 { double v[MAX_ORDER + 1]; };
+
+// change_D (bdf.py:28-33): D[:order + 1] = (R U)^T D[:order + 1];  D: [MAX_ORDER + 3][n]
+__global__ void __launch_bounds__(256) change_D_kernel(double* __restrict__ D, int64_t n, int order, Mat6 RU)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double d[MAX_ORDER + 1];
+#pragma unroll
+    for (int j = 0; j <= MAX_ORDER; j++) d[j] = j <= order ? D[(int64_t)j * n + i] : 0.0;
+#pragma unroll
+    for (int k = 0; k <= MAX_ORDER; k++) {
+        if (k > order) break;
+        double a = 0;
+#pragma unroll
+        for (int j = 0; j <= MAX_ORDER; j++)
+            if (j <= order) a += RU.m[j][k] * d[j];
+        D[(int64_t)k * n + i] = a;
+    }
+}
+
+// y_predict = sum D[:order + 1]; scale = atol + rtol |y_predict|; psi = D[1:order + 1]^T gamma[1:order + 1] / alpha[order]  (bdf.py:358-361)
+// and the start of solve_bdf_system: y = y_predict, d = 0
+__global__ void __launch_bounds__(256) predict_kernel(const double* __restrict__ D, int64_t n, int order, Vec6 gamma, double alpha_order, double rtol,
+                                                      double atol, double* __restrict__ ypred, double* __restrict__ scale, double* __restrict__ psi,
+                                                      double* __restrict__ ynew, double* __restrict__ d)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double a = D[i], q = 0;
+#pragma unroll
+    for (int j = 1; j <= MAX_ORDER; j++)
+        if (j <= order) {
+            const double dj = D[(int64_t)j * n + i];
+            a += dj;
+            q += dj * gamma.v[j];
+        }
+    ypred[i] = a;
+    ynew[i] = a;
+    d[i] = 0;
+    scale[i] = atol + rtol * fabs(a);
+    psi[i] = q / alpha_order;
+}
+
+// restart of the Newton iteration after a Jacobian refresh: y = y_predict, d = 0
+__global__ void __launch_bounds__(256) newton_restart_kernel(const double* __restrict__ ypred, int64_t n, double* __restrict__ ynew, double* __restrict__ d)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    ynew[i] = ypred[i];
+    d[i] = 0;
+}
+
+// right-hand side of the Newton system, cell-major:  c f - psi - d  (bdf.py:48); flags[0] |= a non-finite f
+__global__ void __launch_bounds__(256) newton_rhs_kernel(const double* __restrict__ f, const double* __restrict__ psi, const double* __restrict__ d, int64_t N,
+                                                         double c, double* __restrict__ rhs, int32_t* __restrict__ flags)
+{
+    const int64_t kk = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (kk >= NF * N) return;
+    const int64_t i = radau::to_field_major(kk, N);
+    const double fi = f[i];
+    if (!isfinite(fi)) atomicOr(flags, 1);
+    rhs[kk] = (c * fi - psi[i]) - d[i];
+}
+
+// dy = the solved system (cell-major); out[block] = sum (dy / scale)^2;  y += dy, d += dy  (bdf.py:49, 58-59; when the iteration is
+// abandoned after this norm, y and d are not used any more)
+__global__ void __launch_bounds__(1024) newton_update_kernel(const double* __restrict__ dy_cm, const double* __restrict__ scale, int64_t N,
+                                                             double* __restrict__ ynew, double* __restrict__ d, double* __restrict__ out)
+{
+    __shared__ double red[1024];
+    const int64_t n = NF * N;
+    double ss = 0;
+    for (int64_t kk = (int64_t)blockIdx.x * 1024 + threadIdx.x; kk < n; kk += (int64_t)gridDim.x * 1024) {
+        const int64_t i = radau::to_field_major(kk, N);
+        const double dy = dy_cm[kk];
+        const double e = dy / scale[i];
+        ss += e * e;
+        ynew[i] += dy;
+        d[i] += dy;
+    }
+    red[threadIdx.x] = ss;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
+// out[block] = sum (coef v / (atol + rtol |yref|))^2   (the error norms of bdf.py:398-400, 428-436)
+__global__ void __launch_bounds__(1024) scaled_norm_kernel(const double* __restrict__ v, double coef, const double* __restrict__ yref, double rtol, double atol,
+                                                           int64_t n, double* __restrict__ out)
+{
+    __shared__ double red[1024];
+    double ss = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 1024) {
+        const double e = coef * v[i] / (atol + rtol * fabs(yref[i]));
+        ss += e * e;
+    }
+    red[threadIdx.x] = ss;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
+// the accepted step's update of the differences (bdf.py:419-422); y = y_new
+__global__ void __launch_bounds__(256) accept_kernel(double* __restrict__ D, const double* __restrict__ d, const double* __restrict__ ynew, int64_t n, int order,
+                                                     double* __restrict__ y)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double di = d[i];
+    D[(int64_t)(order + 2) * n + i] = di - D[(int64_t)(order + 1) * n + i];
+    D[(int64_t)(order + 1) * n + i] = di;
+    double above = di;
+    for (int j = order; j >= 0; j--) {
+        const double v = D[(int64_t)j * n + i] + above;
+        D[(int64_t)j * n + i] = v;
+        above = v;
+    }
+    y[i] = ynew[i];
+}
+
+// D[0] = y0, D[1] = f h  (bdf.py:251-254)
+__global__ void __launch_bounds__(256) init_D_kernel(const double* __restrict__ y, const double* __restrict__ f, double h, int64_t n, double* __restrict__ D)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    D[i] = y[i];
+    D[n + i] = f[i] * h;
+}
+
+// BdfDenseOutput._call_impl (bdf.py:465-478): out = D[0] + D[1:order + 1]^T p,  p = cumprod((t - t_shift) / denom)  (computed by the host)
+__global__ void __launch_bounds__(256) dense_kernel(const double* __restrict__ D, int64_t n, int order, Vec6 p, double* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double a = 0;
+#pragma unroll
+    for (int j = 0; j < MAX_ORDER; j++)
+        if (j < order) a += D[(int64_t)(j + 1) * n + i] * p.v[j];
+    out[i] = a + D[i];
+}
+
+}  // namespace bdf
+}  // namespace marl

@@ -432,7 +432,7 @@ __device__ __forceinline__ T gj_inverse_elem(T d, int e, int r, int c, bool act,
 
 // level < 0: blocks of level 0 from J and their inverses; else one PCR level (stride s = 2^level)
 template <class T>
-__device__ void pcr_factor_group(const double* __restrict__ J, int64_t N, int level, T mu, const PcrSystem<T>& S, PcrStage<T>& st)
+__device__ void pcr_factor_group(const double* __restrict__ J, int64_t N, int level, T mu, const PcrSystem<T>& S, PcrStage<T>& st, double jscale = 1.0)
 {
     const int g = threadIdx.x >> 5, e = threadIdx.x & 31;
     const int64_t i = (int64_t)blockIdx.x * PCR_CELLS_PER_BLOCK + g;
@@ -441,12 +441,13 @@ __device__ void pcr_factor_group(const double* __restrict__ J, int64_t N, int le
     const int64_t ic = (i < N) ? i : N - 1;   // idle groups shadow the last cell (uniform barriers, no stores)
     T d;
     if (level < 0) {
-        d = lift(-J[(ic * 3 + 1) * 25 + (act ? e : 0)], mu);
+        // the matrix is  mu I - jscale J  (Radau: mu = MU / h, jscale = 1 - the product with 1.0 is exact; BDF: I - c J)
+        d = lift(-(jscale * J[(ic * 3 + 1) * 25 + (act ? e : 0)]), mu);
         if (r == c) d = d + mu;
         if (act) {
             S.D[0][i * 25 + e] = d;
-            S.L[0][i * 25 + e] = lift(i > 0 ? -J[(i * 3 + 0) * 25 + e] : 0.0, mu);
-            S.U[0][i * 25 + e] = lift(i < N - 1 ? -J[(i * 3 + 2) * 25 + e] : 0.0, mu);
+            S.L[0][i * 25 + e] = lift(i > 0 ? -(jscale * J[(i * 3 + 0) * 25 + e]) : 0.0, mu);
+            S.U[0][i * 25 + e] = lift(i < N - 1 ? -(jscale * J[(i * 3 + 2) * 25 + e]) : 0.0, mu);
         }
         const T inv = gj_inverse_elem<T>(d, e, r, c, act, st);
         if (act) S.Dinv[0][i * 25 + e] = inv;
@@ -495,15 +496,15 @@ __device__ void pcr_factor_group(const double* __restrict__ J, int64_t N, int le
 
 // blockIdx.y: 0 real system, 1 complex system.  level < 0: initialise from J.
 __global__ void __launch_bounds__(256) pcr_factor_kernel(const double* __restrict__ J, int64_t N, int level, double mu_r, cplx mu_c, PcrSystem<double> Sr,
-                                                         PcrSystem<cplx> Sc, ZBatch B = ZBatch{0, nullptr, 0, 0, nullptr})
+                                                         PcrSystem<cplx> Sc, ZBatch B = ZBatch{0, nullptr, 0, 0, nullptr}, double jscale = 1.0)
 {
     if (z_masked_out(B)) return;
     if (B.act) { const RadauCtl* c = ctl_of(B); mu_r = c->mu_r; mu_c = cplx{c->mu_c_re, c->mu_c_im}; }
     J = z_shift(J, B); Sr = z_shift_system(Sr, B); Sc = z_shift_system(Sc, B);
     __shared__ PcrStage<cplx> stage[PCR_CELLS_PER_BLOCK];   // (the real system uses the same bytes)
     const int g = threadIdx.x >> 5;
-    if (blockIdx.y == 0) pcr_factor_group<double>(J, N, level, mu_r, Sr, *reinterpret_cast<PcrStage<double>*>(&stage[g]));
-    else pcr_factor_group<cplx>(J, N, level, mu_c, Sc, stage[g]);
+    if (blockIdx.y == 0) pcr_factor_group<double>(J, N, level, mu_r, Sr, *reinterpret_cast<PcrStage<double>*>(&stage[g]), jscale);
+    else pcr_factor_group<cplx>(J, N, level, mu_c, Sc, stage[g], jscale);
 }
 
 template <class T>

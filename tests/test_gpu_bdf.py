@@ -1,0 +1,86 @@
+"""The implicit BDF path on the GPU (marl_integrate_bdf: scipy's BDF step logic on the host, RHS / finite-difference Jacobian /
+block-tridiagonal factorisation of I - c J by cyclic reduction / every vector operation on the device) against scipy BDF driving the
+REFERENCE's RHS with the reference's jac_sparsity (goldens bdf_traj_*.npz, oracle/make_goldens.py gen_bdf) and against the CPU oracle.
+
+As for Radau (tests/test_gpu_radau.py): where every decision matches scipy's, the states agree closely; one Newton iteration more or
+less at a knife-edge convergence test changes the following step sizes and the solutions then agree like two correct runs do."""
+import json
+
+import numpy as np
+import pytest
+
+from common import GOLDEN
+
+pytestmark = pytest.mark.gpu
+STATE_TOL = 5e-6
+
+
+def _model(name):
+    from dataclasses import asdict
+    from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
+    from marlpde_amd.parameters import Map_Scenario
+    g = np.load(f"{GOLDEN}/bdf_traj_{name}.npz")
+    N = int(g["N"])
+    p = asdict(Map_Scenario()) | json.loads(str(g["overrides"])) | {"N": N}
+    return g, p, LMAHeureuxPorosityDiff.from_scenario(p, device=0)
+
+
+def _close_counts(res, nfev, njev, nlu, steps):
+    return abs(res.nfev - nfev) <= max(6, 0.03 * nfev) and abs(res.njev - njev) <= 2 and abs(res.nlu - nlu) <= 4 and abs(res.n_accepted - steps) <= 3
+
+
+@pytest.mark.parametrize("groups", ["scipy", None])
+@pytest.mark.parametrize("name", ["A", "matlab", "A_N64_tight"])
+def test_bdf_reproduces_scipy_on_the_reference_rhs(oracle, name, groups):
+    g, p, eq = _model(name)
+    N = int(g["N"])
+    grp = oracle.scipy_groups(N) if groups == "scipy" else None
+    res = eq.integrate_bdf(g["y0"], tuple(g["t_span"]), float(g["first_step"]), float(g["rtol"]), float(g["atol"]), t_eval=g["t_span"], groups=grp)
+    eq.close()
+    steps = len(g["step_times"]) - 1
+    print(name, groups, (res.nfev, res.njev, res.nlu, res.n_accepted), "scipy", (int(g["nfev"]), int(g["njev"]), int(g["nlu"]), steps))
+    assert res.status == 0
+    assert _close_counts(res, int(g["nfev"]), int(g["njev"]), int(g["nlu"]), steps)
+    same = (res.nfev, res.njev, res.nlu, res.n_accepted) == (int(g["nfev"]), int(g["njev"]), int(g["nlu"]), steps)
+    tol = STATE_TOL if same else 2 * float(g["rtol"])
+    assert np.max(np.abs(res.y_final - g["y_final"])) <= tol
+    assert np.max(np.abs(res.y[:, 0] - g["y0"])) <= 1e-9 and np.max(np.abs(res.y[:, -1] - g["y_final"])) <= tol
+    if same:
+        assert [len(e) for e in res.t_events] == list(g["n_events"])
+        if sum(g["n_events"]):
+            assert np.max(np.abs(np.concatenate(res.t_events) - g["t_events"])) <= 5e-4
+
+
+def test_bdf_against_the_oracle_on_a_finer_grid(oracle):
+    """N = 1000 (beyond the one-launch solve: per-level cyclic reduction), Scenario A to t = 0.05: the GPU run against the C oracle."""
+    from dataclasses import asdict
+    from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
+    from marlpde_amd.parameters import Map_Scenario
+    N = 1000
+    p = asdict(Map_Scenario()) | {"Phi0": 0.6, "PhiIni": 0.5, "PhiNR": 0.6, "N": N}
+    y0 = np.concatenate([np.full(N, p[k]) for k in ("CAIni", "CCIni", "cCaIni", "cCO3Ini", "PhiIni")])
+    y, st, steps, _, _ = oracle.bdf(oracle.params_from_dict(p), N, y0, 0.0, 0.05, 1e-6, 1e-3, 1e-3)
+    eq = LMAHeureuxPorosityDiff.from_scenario(p, device=0)
+    res = eq.integrate_bdf(y0, (0.0, 0.05), 1e-6, 1e-3, 1e-3, events=False)
+    eq.close()
+    print((res.nfev, res.njev, res.nlu, res.n_accepted), (st.nfev, st.njev, st.nlu, st.n_accepted))
+    assert res.status == st.status == 0
+    assert _close_counts(res, st.nfev, st.njev, st.nlu, st.n_accepted)
+    same = (res.nfev, res.njev, res.nlu, res.n_accepted) == (st.nfev, st.njev, st.nlu, st.n_accepted)
+    assert np.max(np.abs(res.y_final - y)) <= (STATE_TOL if same else 2e-3)
+
+
+def test_integrate_equations_with_bdf_goes_native(tmp_path, monkeypatch):
+    """The drop-in driver with method="BDF": the native path (no scipy solver module involved), result file like the reference's."""
+    import sys
+    from dataclasses import asdict, replace
+    from marlpde_amd.Evolve_scenario import integrate_equations
+    from marlpde_amd.parameters import Map_Scenario, Solver, Tracker
+    monkeypatch.chdir(tmp_path)
+    for m in [m for m in sys.modules if m.startswith("scipy.integrate._ivp")]:
+        del sys.modules[m]
+    sp = asdict(replace(Solver(), method="BDF"))
+    last, covered, depths, Xstar, folder = integrate_equations(sp, asdict(Tracker()), asdict(Map_Scenario()) | {"Phi0": 0.6, "PhiIni": 0.5, "PhiNR": 0.6})
+    assert not any(m.startswith("scipy.integrate._ivp.bdf") for m in sys.modules)
+    gold = np.load(f"{GOLDEN}/bdf_traj_A.npz")["y_final"].reshape(5, 200)
+    np.testing.assert_allclose(last, gold, rtol=0.1, atol=0.01)
