@@ -486,6 +486,26 @@ def main():
                     e["cpu_oracle_nfev_njev_nlu"] = [int(st.nfev), int(st.njev), int(st.nlu)]
                 res[f"N{Nr}"] = e
             extra["implicit_radau_scenarioA_to_Tstar"] = res
+            # the other implicit method of the reference's Solver, scipy BDF semantics (marl_integrate_bdf), same scenario and sizes
+            resb = {}
+            for Nr in (200, 4000, 64000):
+                pr = base | {"Phi0": 0.6, "PhiIni": 0.5, "PhiNR": 0.6, "N": Nr}
+                y0 = np.concatenate([np.full(Nr, pr[k]) for k in ("CAIni", "CCIni", "cCaIni", "cCO3Ini", "PhiIni")])
+                eq = LMAHeureuxPorosityDiff.from_scenario(pr, device=local_rank)
+                eq.use_stream(stream.cuda_stream)
+                eq.integrate_bdf(y0, (0.0, 1e-4), 1e-6, 1e-3, 1e-3, events=False)
+                t0 = time.perf_counter()
+                r = eq.integrate_bdf(y0, (0.0, 1.0), 1e-6, 1e-3, 1e-3)
+                e = {"seconds": time.perf_counter() - t0, "status": r.status, "steps": r.n_accepted, "nfev": r.nfev, "njev": r.njev, "nlu": r.nlu}
+                eq.close()
+                if rank == 0 and Nr <= 4000 and not args.no_cpu_baseline:
+                    from oracle import oracle as orc
+                    t0 = time.perf_counter()
+                    _, st, *_ = orc.bdf(orc.params_from_dict(pr), Nr, y0, 0.0, 1.0, 1e-6, 1e-3, 1e-3)
+                    e["cpu_oracle_seconds_1_core"] = time.perf_counter() - t0
+                    e["cpu_oracle_nfev_njev_nlu"] = [int(st.nfev), int(st.njev), int(st.nlu)]
+                resb[f"N{Nr}"] = e
+            extra["implicit_bdf_scenarioA_to_Tstar"] = resb
             # a SWEEP with the same solver: 512 scenarios (Phi0 x PhiIni x k3 = k4 grid), N = 200, all advanced together
             Bs, Ns = 512, 200
             kk = 8
