@@ -505,6 +505,8 @@ def main():
                     e["cpu_oracle_seconds_1_core"] = time.perf_counter() - t0
                     e["cpu_oracle_nfev_njev_nlu"] = [int(st.nfev), int(st.njev), int(st.nlu)]
                 resb[f"N{Nr}"] = e
+            resb["note"] = ("status -1 on the finer grids is the METHOD: scipy's BDF itself stops at t = 0.0853 T* with 'Required step size is less than spacing "
+                            "between numbers' at N = 4000 (rtol = atol = 1e-3); the oracle and the GPU path reproduce it (DESIGN.md 8)")
             extra["implicit_bdf_scenarioA_to_Tstar"] = resb
             # a SWEEP with the same solver: 512 scenarios (Phi0 x PhiIni x k3 = k4 grid), N = 200, all advanced together
             Bs, Ns = 512, 200
