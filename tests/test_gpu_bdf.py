@@ -84,3 +84,23 @@ def test_integrate_equations_with_bdf_goes_native(tmp_path, monkeypatch):
     assert not any(m.startswith("scipy.integrate._ivp.bdf") for m in sys.modules)
     gold = np.load(f"{GOLDEN}/bdf_traj_A.npz")["y_final"].reshape(5, 200)
     np.testing.assert_allclose(last, gold, rtol=0.1, atol=0.01)
+
+
+def test_bdf_breakdown_on_a_finer_grid_is_reproduced(oracle):
+    """scipy's BDF breaks down on this model on finer grids at rtol = atol = 1e-3: at N = 4000 it returns status -1 ("Required step
+    size is less than spacing between numbers") at t = 0.0853225 T* (688 / 53 / 134 evaluations / Jacobians / factorisations with
+    scipy 1.15 driving the oracle's RHS).  The oracle and the GPU path reproduce the failure - same status, same time."""
+    from dataclasses import asdict
+    from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
+    from marlpde_amd.parameters import Map_Scenario
+    N = 4000
+    p = asdict(Map_Scenario()) | {"Phi0": 0.6, "PhiIni": 0.5, "PhiNR": 0.6, "N": N}
+    y0 = np.concatenate([np.full(N, p[k]) for k in ("CAIni", "CCIni", "cCaIni", "cCO3Ini", "PhiIni")])
+    _, st, *_ = oracle.bdf(oracle.params_from_dict(p), N, y0, 0.0, 1.0, 1e-6, 1e-3, 1e-3)
+    eq = LMAHeureuxPorosityDiff.from_scenario(p, device=0)
+    res = eq.integrate_bdf(y0, (0.0, 1.0), 1e-6, 1e-3, 1e-3, events=False)
+    eq.close()
+    print((res.status, res.t_reached, res.nfev, res.njev, res.nlu), (st.status, st.t, st.nfev, st.njev, st.nlu))
+    assert res.status == st.status == -1
+    assert abs(res.t_reached - 0.0853225) <= 1e-5 and abs(st.t - 0.0853225) <= 1e-5
+    assert abs(res.nfev - st.nfev) <= 0.05 * st.nfev
