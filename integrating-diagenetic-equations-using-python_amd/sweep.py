@@ -40,6 +40,13 @@ class HipSweepEngine:
         res = self.model.sweep_rk45_device(yd.data_ptr(), t_span, first_step, rtol, atol, max_attempts)
         return yd.cpu().numpy(), res
 
+    def integrate_radau(self, y0, t_span, first_step, rtol, atol, max_attempts):
+        """The reference's default solver over the shard: every instance its own Radau step logic, advanced together on the device
+        (marl_sweep_radau_dev).  Returns (y_final (n_local, 5N), list of RK45Result)."""
+        yd = self.torch.from_numpy(np.ascontiguousarray(y0)).to(self.device)
+        res = self.model.sweep_radau_device(yd.data_ptr(), t_span, first_step, rtol, atol, max_attempts)
+        return yd.cpu().numpy(), res
+
     def integrate_rk4(self, y0, dt, nsteps):
         yd = self.torch.from_numpy(np.ascontiguousarray(y0)).to(self.device)
         self.model.sweep_rk4_device(yd.data_ptr(), dt, nsteps)
@@ -60,6 +67,13 @@ def initial_states(base_parms, instances):
     return out
 
 
+def run_sweep_radau(base_parms, instances, t_span, first_step, rtol, atol, max_attempts=0, y0=None, group=None,
+                    device=None, engine_factory=None, gather=True):
+    """As :func:`run_sweep_rk45` with the reference's DEFAULT solver (scipy Radau semantics, marlpde/parameters.py:213): what the
+    reference does one scenario per process (its tests loop over scenarios), sharded over the ranks with no data-path collective."""
+    return _run_sweep("integrate_radau", base_parms, instances, t_span, first_step, rtol, atol, max_attempts, y0, group, device, engine_factory, gather)
+
+
 def run_sweep_rk45(base_parms, instances, t_span, first_step, rtol, atol, max_attempts=0, y0=None, group=None,
                    device=None, engine_factory=None, gather=True):
     """Integrate every instance with adaptive RK45; ranks of ``group`` each take a contiguous shard.
@@ -67,6 +81,10 @@ def run_sweep_rk45(base_parms, instances, t_span, first_step, rtol, atol, max_at
     Returns ``(y_final, status, n_accepted, n_rejected, t_reached)`` - for ALL instances when ``gather``,
     otherwise for the local shard.  ``engine_factory(base_parms, local_instances) -> engine`` is the test hook;
     the default is :class:`HipSweepEngine` on ``cuda:rank``."""
+    return _run_sweep("integrate_rk45", base_parms, instances, t_span, first_step, rtol, atol, max_attempts, y0, group, device, engine_factory, gather)
+
+
+def _run_sweep(method, base_parms, instances, t_span, first_step, rtol, atol, max_attempts, y0, group, device, engine_factory, gather):
     import torch.distributed as dist
     on = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank(group) if on else 0
@@ -79,7 +97,7 @@ def run_sweep_rk45(base_parms, instances, t_span, first_step, rtol, atol, max_at
         dev = int(os.environ.get("LOCAL_RANK", rank)) if device is None else device   # one process per GPU
         engine_factory = lambda bp, inst: HipSweepEngine(bp, inst, dev)  # noqa: E731
     engine = engine_factory(base_parms, local)
-    y, res = engine.integrate_rk45(np.asarray(y0)[lo:hi], t_span, first_step, rtol, atol, max_attempts)
+    y, res = getattr(engine, method)(np.asarray(y0)[lo:hi], t_span, first_step, rtol, atol, max_attempts)
     engine.close()
     summary = np.array([[r.status, r.n_accepted, r.n_rejected, r.t_reached] for r in res], dtype=float).reshape(len(local), 4)
     if gather and world > 1:

@@ -30,6 +30,15 @@ class OracleSweepEngine:
             res.append(RK45Result(st))
         return np.array(ys).reshape(len(self.P), 5 * self.N), res
 
+    def integrate_radau(self, y0, t_span, first_step, rtol, atol, max_attempts):
+        from marlpde_amd.LHeureux_model import RK45Result
+        ys, res = [], []
+        for P, y in zip(self.P, y0):
+            yf, st, *_ = orc.radau(P, self.N, y, t_span[0], t_span[1], first_step, rtol, atol, max_attempts=max_attempts)
+            ys.append(yf)
+            res.append(RK45Result(st))
+        return np.array(ys).reshape(len(self.P), 5 * self.N), res
+
     def close(self):
         pass
 

@@ -238,3 +238,25 @@ def test_radau_sweep_of_512_scenarios_properties(torch_cuda_radau):
         ref = one.integrate_radau(y0[b], (0.0, 1.0), 1e-6, 1e-3, 1e-3, events=False)
         one.close()
         np.testing.assert_allclose(got[b].ravel(), ref.y_final, rtol=0.1, atol=0.01)
+
+
+def test_run_sweep_radau_driver_on_the_gpu(torch_cuda_radau):
+    """marlpde_amd.sweep.run_sweep_radau (one rank here; shards over the ranks of a torch.distributed job, tests/test_multi_rank_cpu.py):
+    the same numbers as the model's own sweep entry point."""
+    torch = torch_cuda_radau
+    from dataclasses import asdict
+    from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
+    from marlpde_amd.parameters import Map_Scenario
+    from marlpde_amd.sweep import initial_states, product_grid, run_sweep_radau
+    N = 200
+    base = asdict(Map_Scenario()) | {"N": N}
+    insts = product_grid(Phi0=[0.55, 0.65], k3=[0.02, 0.08])
+    for d in insts:
+        d.update(PhiIni=d["Phi0"], PhiNR=d["Phi0"], k4=d["k3"])
+    y, status, acc, rej, t = run_sweep_radau(base, insts, (0.0, 1.0), 1e-6, 1e-3, 1e-3, device=0)
+    eq = LMAHeureuxPorosityDiff.from_scenario(base, device=0, instances=insts)
+    yd = torch.from_numpy(initial_states(base, insts)).cuda()
+    res = eq.sweep_radau_device(yd.data_ptr(), (0.0, 1.0), 1e-6, 1e-3, 1e-3)
+    eq.close()
+    assert list(status) == [0] * 4 and np.all(t == 1.0)
+    assert np.array_equal(y, yd.cpu().numpy()) and list(acc) == [r.n_accepted for r in res]

@@ -83,6 +83,35 @@ def test_sweep_shards_without_collectives_and_gathers(oracle):
             assert np.array_equal(y[i], yref) and (acc[i], rej[i]) == (st.n_accepted, st.n_rejected) and t[i] == st.t
 
 
+def _radau_sweep_worker(rank, world, N, insts):
+    from cpu_engines import OracleSweepEngine
+    from marlpde_amd.sweep import run_sweep_radau, shard
+    base = scenario("default", N)
+    y, status, acc, rej, t = run_sweep_radau(base, insts, (0.0, 0.05), 1e-6, 1e-3, 1e-3,
+                                             engine_factory=lambda bp, inst: OracleSweepEngine(bp, inst))
+    return y, status, acc, rej, t, shard(len(insts), rank, world)
+
+
+def test_radau_sweep_shards_without_collectives_and_gathers(oracle):
+    """The same sharding for the reference's default solver (run_sweep_radau): 5 scenarios over 2 ranks, every rank ends with all results."""
+    from marlpde_amd.sweep import product_grid
+    N = 32
+    insts = product_grid(Phi0=[0.5, 0.6, 0.7, 0.75, 0.8])
+    for d in insts:
+        d.update(PhiIni=d["Phi0"], PhiNR=d["Phi0"])
+    out = _spawn(_radau_sweep_worker, 2, N, insts)
+    assert out[0][5] == (0, 2) and out[1][5] == (2, 5)
+    base = scenario("default", N)
+    for r in (0, 1):
+        y, status, acc, rej, t, _ = out[r]
+        assert y.shape == (5, 5 * N) and list(status) == [0] * 5 and np.all(t == 0.05)
+        for i, inst in enumerate(insts):
+            p = base | inst
+            y0 = np.repeat([p["CAIni"], p["CCIni"], p["cCaIni"], p["cCO3Ini"], p["PhiIni"]], N)
+            yref, st, *_ = oracle.radau(oracle.params_from_dict(p), N, y0, 0.0, 0.05, 1e-6, 1e-3, 1e-3)
+            assert np.array_equal(y[i], yref) and (acc[i], rej[i]) == (st.n_accepted, st.n_rejected)
+
+
 # ---- domain decomposition ----------------------------------------------------------------------------
 def _dd_worker(rank, world, N, t1, first_step, rtol, atol, max_attempts):
     from cpu_engines import OracleSlabEngine
