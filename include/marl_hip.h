@@ -54,6 +54,8 @@ int marl_synchronize(marl_ctx* ctx);
  *   host-pointer entry points), poll_interval (attempts enqueued between status reads), no_reuse (1: every RHS evaluation of
  *   the fused kernels takes its full transcendental path - the input-independent worst case, for benchmarks), radau_solver
  *   (linear systems of the implicit path: 0 block parallel cyclic reduction - the default -, 1 sequential block Thomas),
+ *   implicit_zero_copy (1, the default: marl_integrate_radau / marl_integrate_bdf read their per-iteration scalars from coherent host
+ *   memory that the kernels write and the host polls; 0: a copy and a stream synchronisation per read - bit-identical),
  *   radau_fused_solve (1, the default: systems of up to 2048 unknowns run every cyclic-reduction level of a solve in one
  *   launch; 0: one launch per level - bit-identical),
  *   rk4_stream (fixed-step RK4 of one grid as ONE dataflow launch over (level, tile) work items instead of one launch per

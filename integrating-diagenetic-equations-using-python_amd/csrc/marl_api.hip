@@ -69,9 +69,16 @@ struct marl_ctx {
     double* rd_arena = nullptr;
     size_t rd_cap = 0;
     double* rd_host = nullptr;  // pinned: [0] norm^2, [1] flags (as int32), [2..] spare
+    // zero-copy result words of the single-instance implicit drivers: coherent host memory the kernels write their scalar results
+    // into and the host polls - no copy, no stream synchronisation per Newton iteration.  [0] a sum of squares, [1] the non-finite flag
+    // (int32), [8..15] a monitors record.  A slot is "armed" with a NaN of a payload no computation produces until its kernel writes it.
+    double* zc_h = nullptr;     // host view
+    double* zc_d = nullptr;     // device view of the same memory
+    bool zc_on = false;         // the run in progress uses it
     // options
     int64_t rk4_variant = -1, rk45_variant = -1, sweep_variant = -1, host_layout = LAYOUT_TILED, poll = 64;
     int64_t rk4_stream = 1;     // the fixed-step loop of one grid as ONE dataflow launch (rk4_stream_kernel): 0 never, 1 large grids, 2 always
+    int64_t implicit_zero_copy = 1;  // scalar results of the implicit drivers through polled host memory (0: copy + synchronise)
     int64_t radau_fused_solve = 1;   // small systems (5 N <= 2048): all PCR levels of a solve in one launch
     int64_t radau_solver = 0;   // 0: block parallel cyclic reduction (parallel over depth); 1: sequential block Thomas
     std::string err;
@@ -268,6 +275,7 @@ void marl_ctx_destroy(marl_ctx* ctx)
     if (ctx->dd_recs) (void)hipFree(ctx->dd_recs);
     if (ctx->rd_arena) (void)hipFree(ctx->rd_arena);
     if (ctx->rd_host) (void)hipHostFree(ctx->rd_host);
+    if (ctx->zc_h) (void)hipHostFree(ctx->zc_h);
     delete ctx;
 }
 
@@ -315,6 +323,7 @@ int marl_set_option(marl_ctx* ctx, const char* name, int64_t value)
     else if (n == "poll_interval") ctx->poll = value > 0 ? value : 1;
     else if (n == "radau_solver") ctx->radau_solver = value ? 1 : 0;
     else if (n == "radau_fused_solve") ctx->radau_fused_solve = value ? 1 : 0;
+    else if (n == "implicit_zero_copy") ctx->implicit_zero_copy = value ? 1 : 0;
     else if (n == "rk4_stream") ctx->rk4_stream = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "rk4_stream_test_raise") ctx->sq_test_raise = value != 0;
     else if (n == "rk4_stream_max_items") ctx->sq_max_items = value > 0 ? std::min<int64_t>(value, 0x7fffffff) : 0x7fffffff;
@@ -389,7 +398,7 @@ static int launch_convert(marl_ctx* ctx, const double* src, double* dst, int sl,
 }
 
 // monitors of `y` -> ctx->rec[batch][NQ] (device)
-static int launch_monitors(marl_ctx* ctx, const double* y, int layout)
+static int launch_monitors(marl_ctx* ctx, const double* y, int layout, double* rec_out = nullptr)
 {
     const int64_t n = ctx->slab.out_hi - ctx->slab.out_lo;
     int64_t nb = (n + 255) / 256;
@@ -401,7 +410,7 @@ static int launch_monitors(marl_ctx* ctx, const double* y, int layout)
     else
         hipLaunchKernelGGL(monitors_kernel<LAYOUT_FIELD_MAJOR>, grid, dim3(256), 0, ctx->stream, y, ctx->dconsts, ctx->slab, inst_stride(ctx, layout), ctx->part);
     LAUNCH_OK(ctx);
-    hipLaunchKernelGGL(reduce_records_kernel, dim3((unsigned)ctx->batch), dim3(256), 0, ctx->stream, ctx->part, nb, ctx->rec);
+    hipLaunchKernelGGL(reduce_records_kernel, dim3((unsigned)ctx->batch), dim3(256), 0, ctx->stream, ctx->part, nb, rec_out ? rec_out : ctx->rec);
     LAUNCH_OK(ctx);
     return 0;
 }
@@ -1341,6 +1350,27 @@ struct RadauWork {
     bool pcr = true;
 };
 
+// Zero-copy slots: arm = store the sentinel; wait = poll until the kernel has overwritten it (bounded, then fall back to a synchronise).
+constexpr uint64_t kZcSentinel = 0x7ff8dead5eed0001ull;   // a quiet NaN with a payload arithmetic does not produce
+inline void zc_arm(marl_ctx* ctx, int slot, int count = 1)
+{
+    for (int i = 0; i < count; i++) reinterpret_cast<volatile uint64_t*>(ctx->zc_h)[slot + i] = kZcSentinel;
+}
+inline int zc_wait(marl_ctx* ctx, int slot, int count = 1)
+{
+    volatile uint64_t* p = reinterpret_cast<volatile uint64_t*>(ctx->zc_h);
+    for (int i = 0; i < count; i++) {
+        int64_t spins = 0;
+        while (p[slot + i] == kZcSentinel) {
+            if (++spins > (int64_t)1 << 28) {   // ~seconds: something is wrong with the stream - let the runtime say what
+                HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+                if (p[slot + i] == kZcSentinel) return fail(ctx, -3, "implicit driver: a result word was never written");
+            }
+        }
+    }
+    return 0;
+}
+
 // `instances` > 1: one arena per instance, all with the layout of instance 0 (`w`), `*zstride` bytes apart
 int radau_alloc(marl_ctx* ctx, RadauWork& w, const int32_t* groups_host, int64_t instances = 1, int64_t* zstride = nullptr)
 {
@@ -1385,6 +1415,19 @@ int radau_alloc(marl_ctx* ctx, RadauWork& w, const int32_t* groups_host, int64_t
     w.Dinv_c = (cplx*)take(10 * n); w.Up_c = (cplx*)take(10 * n);
     w.rhs_r = take(n); w.rhs_c = (cplx*)take(2 * n); w.out = take(8); w.partial = take(kRadauPartials);
     w.small = (int32_t*)take((n + 1) / 2 + 1); w.groups = (int32_t*)take((n + 1) / 2 + 1); w.flags = (int32_t*)take(2);
+    ctx->zc_on = false;
+    if (instances == 1 && ctx->implicit_zero_copy) {
+        if (!ctx->zc_h) {
+            HIP_OK(ctx, hipHostMalloc((void**)&ctx->zc_h, 32 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+            HIP_OK(ctx, hipHostGetDevicePointer((void**)&ctx->zc_d, ctx->zc_h, 0));
+        }
+        HIP_OK(ctx, hipStreamSynchronize(ctx->stream));   // nothing of an earlier run may still write the words
+        memset(ctx->zc_h, 0, 32 * sizeof(double));
+        zc_arm(ctx, 0);
+        w.out = ctx->zc_d;
+        w.flags = reinterpret_cast<int32_t*>(ctx->zc_d + 1);
+        ctx->zc_on = true;
+    }
     w.ng = ng;
     w.nlevels = nlev;
     w.pcr = ctx->radau_solver == 0;
@@ -1493,6 +1536,15 @@ int radau_error_norm(marl_ctx* ctx, RadauWork& w, double rtol, double atol)
 // read back w.out[0] (a sum of squares) and the non-finite flag; resets the flag
 int radau_read(marl_ctx* ctx, RadauWork& w, double* sumsq, int* flag)
 {
+    if (ctx->zc_on) {
+        if (int rc = zc_wait(ctx, 0)) return rc;
+        *sumsq = const_cast<const volatile double*>(ctx->zc_h)[0];
+        volatile int32_t* fl = reinterpret_cast<volatile int32_t*>(ctx->zc_h + 1);
+        if (flag) *flag = *fl;
+        if (*fl) *fl = 0;     // (every kernel that could set it has completed: the word that was waited for is written after them)
+        zc_arm(ctx, 0);       // for the next producer
+        return 0;
+    }
     HIP_OK(ctx, hipMemcpyAsync(ctx->rd_host, w.out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_OK(ctx, hipMemcpyAsync(ctx->rd_host + 1, w.flags, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1506,6 +1558,15 @@ int radau_read(marl_ctx* ctx, RadauWork& w, double* sumsq, int* flag)
 
 int radau_monitors(marl_ctx* ctx, const double* y, double g[7])
 {
+    if (ctx->zc_on) {
+        zc_arm(ctx, 8, NQ);
+        if (int rc = launch_monitors(ctx, y, LAYOUT_FIELD_MAJOR, ctx->zc_d + 8)) return rc;
+        if (int rc = zc_wait(ctx, 8, NQ)) return rc;
+        double r[NQ];
+        for (int j = 0; j < NQ; j++) r[j] = const_cast<const volatile double*>(ctx->zc_h)[8 + j];
+        record_to_events(r, g);
+        return 0;
+    }
     if (int rc = launch_monitors(ctx, y, LAYOUT_FIELD_MAJOR)) return rc;
     HIP_OK(ctx, hipMemcpyAsync(ctx->hrec, ctx->rec, sizeof(double) * NQ, hipMemcpyDeviceToHost, ctx->stream));
     HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1598,7 +1659,7 @@ int radau_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_st
     st->nfev = 1;
     double S_h_abs = first_step, S_h_abs_old = -1, S_err_old = -1;
     const double newton_tol = std::fmax(10 * radau::EPS / rtol, std::fmin(0.03, std::sqrt(rtol)));
-    HIP_OK(ctx, hipMemsetAsync(w.flags, 0, sizeof(int32_t) * 2, ctx->stream));
+    if (!ctx->zc_on) HIP_OK(ctx, hipMemsetAsync(w.flags, 0, sizeof(int32_t) * 2, ctx->stream));
     if (int rc = radau_num_jac(ctx, w, w.y, w.f, atol)) return rc;
     st->njev = 1;
     bool current_jac = true, have_lu = false, have_sol = false;
@@ -1902,7 +1963,7 @@ int bdf_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_step
     st->nfev = 1;
     double S_h_abs = first_step;
     const double newton_tol = std::fmax(10 * radau::EPS / rtol, std::fmin(0.03, std::sqrt(rtol)));
-    HIP_OK(ctx, hipMemsetAsync(w.flags, 0, sizeof(int32_t) * 2, ctx->stream));
+    if (!ctx->zc_on) HIP_OK(ctx, hipMemsetAsync(w.flags, 0, sizeof(int32_t) * 2, ctx->stream));
     // jac_wrapped(t0, y0): f = fun_single(t, y) (not counted; the same values as w.f), J by finite differences
     if (int rc = radau_num_jac(ctx, w, w.y, w.f, atol)) return rc;
     st->njev = 1;

@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(256) newton_rhs_kernel(const double* __restric
     if (kk >= NF * N) return;
     const int64_t i = radau::to_field_major(kk, N);
     const double fi = f[i];
-    if (!isfinite(fi)) atomicOr(flags, 1);
+    if (!isfinite(fi)) *flags = 1;
     rhs[kk] = (c * fi - psi[i]) - d[i];
 }
 

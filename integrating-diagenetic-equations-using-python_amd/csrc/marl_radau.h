@@ -612,7 +612,7 @@ __global__ void __launch_bounds__(256) newton_rhs_kernel(const double* __restric
     if (kk >= n) return;
     const int64_t i = to_field_major(kk, N);
     const double f0 = F[i], f1 = F[n + i], f2 = F[2 * n + i];
-    if (!(isfinite(f0) && isfinite(f1) && isfinite(f2))) atomicOr(flags, 1);
+    if (!(isfinite(f0) && isfinite(f1) && isfinite(f2))) *flags = 1;   // (a plain store: racing stores of the same value; the word may live in host memory)
     rhs_r[kk] = ((f0 * TI00 + f1 * TI01) + f2 * TI02) - M_real * W[i];
     const cplx w = {W[n + i], W[2 * n + i]};
     const cplx fc = {(f0 * TI10 + f1 * TI11) + f2 * TI12, (f0 * TI20 + f1 * TI21) + f2 * TI22};

@@ -104,3 +104,20 @@ def test_bdf_breakdown_on_a_finer_grid_is_reproduced(oracle):
     assert res.status == st.status == -1
     assert abs(res.t_reached - 0.0853225) <= 1e-5 and abs(st.t - 0.0853225) <= 1e-5
     assert abs(res.nfev - st.nfev) <= 0.05 * st.nfev
+
+
+@pytest.mark.parametrize("method", ["integrate_radau", "integrate_bdf"])
+def test_zero_copy_result_words_change_nothing(method):
+    """The single-instance implicit drivers read their per-iteration scalars (a sum of squares, the non-finite flag, the monitors
+    record) from coherent host memory that the kernels write and the host polls (option implicit_zero_copy, default 1) instead of a
+    copy + stream synchronisation per Newton iteration: same kernels, same numbers - the runs must be bit-identical."""
+    g, p, eq = _model("A")
+    out = []
+    for zc in (0, 1):
+        eq.set_option("implicit_zero_copy", zc)
+        out.append(getattr(eq, method)(g["y0"], tuple(g["t_span"]), float(g["first_step"]), float(g["rtol"]), float(g["atol"])))
+    eq.close()
+    a, b = out
+    assert (a.status, a.nfev, a.njev, a.nlu, a.n_accepted) == (b.status, b.nfev, b.njev, b.nlu, b.n_accepted)
+    assert np.array_equal(a.y_final, b.y_final)
+    assert all(np.array_equal(x, y) for x, y in zip(a.t_events, b.t_events))
