@@ -2256,6 +2256,15 @@ extern "C" int marl_sweep_radau_dev(marl_ctx* ctx, double* y_dev, double t0, dou
     if (int rc = ensure_part(ctx, (size_t)(nbm * B))) { cleanup(); return rc; }
     int rc_out = 0;
     int32_t* hcounts = reinterpret_cast<int32_t*>(ctx->rd_host);
+    volatile int32_t* zc_words = nullptr;
+    if (ctx->implicit_zero_copy) {
+        if (!ctx->zc_h) {
+            if (hipHostMalloc((void**)&ctx->zc_h, 32 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+                hipHostGetDevicePointer((void**)&ctx->zc_d, ctx->zc_h, 0) != hipSuccess) { cleanup(); return fail(ctx, -3, "host allocation failed"); }
+        }
+        zc_words = reinterpret_cast<volatile int32_t*>(ctx->zc_h + 16);
+        zc_words[radau::L_COUNT] = 0;
+    }
     using namespace radau;
 #define RB_OK()                                                                                       \
     do {                                                                                              \
@@ -2268,8 +2277,20 @@ extern "C" int marl_sweep_radau_dev(marl_ctx* ctx, double* y_dev, double t0, dou
         (void)hipMemsetAsync(dcounts, 0, sizeof(int32_t) * L_COUNT, ctx->stream);
         hipLaunchKernelGGL(radau_control_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, ctx->stream, dctl, drec, B, n, dcounts, dlists);
         RB_OK();
-        (void)hipMemcpyAsync(hcounts, dcounts, sizeof(int32_t) * L_COUNT, hipMemcpyDeviceToHost, ctx->stream);
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { cleanup(); return fail(ctx, -3, "synchronize failed"); }
+        if (zc_words) {   // the list lengths through polled host memory
+            hipLaunchKernelGGL(publish_counts_kernel, dim3(1), dim3(1), 0, ctx->stream, dcounts, reinterpret_cast<int32_t*>(ctx->zc_d + 16), (int32_t)(cycle + 1));
+            RB_OK();
+            int64_t spins = 0;
+            while (zc_words[L_COUNT] != (int32_t)(cycle + 1)) {
+                if (++spins > (int64_t)1 << 28) {
+                    if (hipStreamSynchronize(ctx->stream) != hipSuccess || zc_words[L_COUNT] != (int32_t)(cycle + 1)) { cleanup(); return fail(ctx, -3, "sweep: the work-list lengths never arrived"); }
+                }
+            }
+            for (int i = 0; i < L_COUNT; i++) hcounts[i] = zc_words[i];
+        } else {
+            (void)hipMemcpyAsync(hcounts, dcounts, sizeof(int32_t) * L_COUNT, hipMemcpyDeviceToHost, ctx->stream);
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess) { cleanup(); return fail(ctx, -3, "synchronize failed"); }
+        }
         if (hcounts[L_RUNNING] == 0) break;
         const unsigned nR = (unsigned)hcounts[L_RHS1], nA = (unsigned)hcounts[L_ACCEPT], nJ = (unsigned)hcounts[L_JAC], nL = (unsigned)hcounts[L_LU],
                        nN = (unsigned)hcounts[L_NEWTON], nE = (unsigned)hcounts[L_ERR];

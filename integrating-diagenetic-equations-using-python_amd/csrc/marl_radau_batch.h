@@ -395,5 +395,13 @@ __global__ void __launch_bounds__(1024) error_norm_batch_kernel(const double* __
     if (threadIdx.x == 0) ctls[z_inst(B)].sumsq = red[0];
 }
 
+// The work-list lengths of a cycle for the host: into coherent host memory (the host polls `seq`; no copy, no stream synchronisation)
+__global__ void publish_counts_kernel(const int32_t* __restrict__ counts, int32_t* __restrict__ host_words, int32_t seq)
+{
+    for (int i = 0; i < L_COUNT; i++) host_words[i] = counts[i];
+    __threadfence_system();
+    *reinterpret_cast<volatile int32_t*>(host_words + L_COUNT) = seq;
+}
+
 }  // namespace radau
 }  // namespace marl
