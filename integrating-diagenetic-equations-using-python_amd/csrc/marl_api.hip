@@ -2274,7 +2274,7 @@ extern "C" int marl_sweep_radau_dev(marl_ctx* ctx, double* y_dev, double t0, dou
     for (int64_t cycle = 0;; cycle++) {
         // the controllers advance every instance to its next piece of work and sort the instances into work lists; the host
         // reads the list lengths (one small copy + synchronisation per cycle) and launches each kind of work over its list only
-        (void)hipMemsetAsync(dcounts, 0, sizeof(int32_t) * L_COUNT, ctx->stream);
+        if (!zc_words || cycle == 0) (void)hipMemsetAsync(dcounts, 0, sizeof(int32_t) * L_COUNT, ctx->stream);   // (publish_counts_kernel zeroes them afterwards)
         hipLaunchKernelGGL(radau_control_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, ctx->stream, dctl, drec, B, n, dcounts, dlists);
         RB_OK();
         if (zc_words) {   // the list lengths through polled host memory

@@ -396,9 +396,10 @@ __global__ void __launch_bounds__(1024) error_norm_batch_kernel(const double* __
 }
 
 // The work-list lengths of a cycle for the host: into coherent host memory (the host polls `seq`; no copy, no stream synchronisation)
-__global__ void publish_counts_kernel(const int32_t* __restrict__ counts, int32_t* __restrict__ host_words, int32_t seq)
+// ... and zeroes them for the next cycle's controllers (one launch less per cycle than a memset in front of the control kernel)
+__global__ void publish_counts_kernel(int32_t* __restrict__ counts, int32_t* __restrict__ host_words, int32_t seq)
 {
-    for (int i = 0; i < L_COUNT; i++) host_words[i] = counts[i];
+    for (int i = 0; i < L_COUNT; i++) { host_words[i] = counts[i]; counts[i] = 0; }
     __threadfence_system();
     *reinterpret_cast<volatile int32_t*>(host_words + L_COUNT) = seq;
 }
