@@ -1362,6 +1362,9 @@ inline int zc_wait(marl_ctx* ctx, int slot, int count = 1)
     for (int i = 0; i < count; i++) {
         int64_t spins = 0;
         while (p[slot + i] == kZcSentinel) {
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
             if (++spins > (int64_t)1 << 28) {   // ~seconds: something is wrong with the stream - let the runtime say what
                 HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
                 if (p[slot + i] == kZcSentinel) return fail(ctx, -3, "implicit driver: a result word was never written");
@@ -2282,6 +2285,9 @@ extern "C" int marl_sweep_radau_dev(marl_ctx* ctx, double* y_dev, double t0, dou
             RB_OK();
             int64_t spins = 0;
             while (zc_words[L_COUNT] != (int32_t)(cycle + 1)) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
                 if (++spins > (int64_t)1 << 28) {
                     if (hipStreamSynchronize(ctx->stream) != hipSuccess || zc_words[L_COUNT] != (int32_t)(cycle + 1)) { cleanup(); return fail(ctx, -3, "sweep: the work-list lengths never arrived"); }
                 }
