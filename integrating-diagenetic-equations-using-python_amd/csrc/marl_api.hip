@@ -405,12 +405,15 @@ static int launch_monitors(marl_ctx* ctx, const double* y, int layout, double* r
     if (nb > 1024) nb = 1024;
     if (int rc = ensure_part(ctx, (size_t)(nb * ctx->batch))) return rc;
     const dim3 grid((unsigned)nb, (unsigned)ctx->batch);
+    double* rec = rec_out ? rec_out : ctx->rec;
+    double* first = nb == 1 ? rec : ctx->part;   // one workgroup per instance (N <= 256): its record IS the result - no second level
     if (layout == LAYOUT_TILED)
-        hipLaunchKernelGGL(monitors_kernel<LAYOUT_TILED>, grid, dim3(256), 0, ctx->stream, y, ctx->dconsts, ctx->slab, inst_stride(ctx, layout), ctx->part);
+        hipLaunchKernelGGL(monitors_kernel<LAYOUT_TILED>, grid, dim3(256), 0, ctx->stream, y, ctx->dconsts, ctx->slab, inst_stride(ctx, layout), first);
     else
-        hipLaunchKernelGGL(monitors_kernel<LAYOUT_FIELD_MAJOR>, grid, dim3(256), 0, ctx->stream, y, ctx->dconsts, ctx->slab, inst_stride(ctx, layout), ctx->part);
+        hipLaunchKernelGGL(monitors_kernel<LAYOUT_FIELD_MAJOR>, grid, dim3(256), 0, ctx->stream, y, ctx->dconsts, ctx->slab, inst_stride(ctx, layout), first);
     LAUNCH_OK(ctx);
-    hipLaunchKernelGGL(reduce_records_kernel, dim3((unsigned)ctx->batch), dim3(256), 0, ctx->stream, ctx->part, nb, rec_out ? rec_out : ctx->rec);
+    if (nb == 1) return 0;
+    hipLaunchKernelGGL(reduce_records_kernel, dim3((unsigned)ctx->batch), dim3(256), 0, ctx->stream, ctx->part, nb, rec);
     LAUNCH_OK(ctx);
     return 0;
 }
