@@ -2036,6 +2036,11 @@ int bdf_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_step
                 for (k = 0; k < NEWTON_MAXITER; k++) {
                     if (int rc = launch_rhs(ctx, w.ynew, f, LAYOUT_FIELD_MAJOR)) return rc;
                     st->nfev++;
+                    if (n <= radau::PCR_FUSED_MAX && ctx->radau_fused_solve) {   // right-hand side + every level + update + norm in one launch
+                        hipLaunchKernelGGL(bdf::newton_fused_kernel, dim3(1), dim3(radau::PCR_FUSED_THREADS), 0, ctx->stream, f, psi, N, c, w.nlevels, w.Sr, w.scale,
+                                           w.ynew, d, w.flags, w.out);
+                        LAUNCH_OK(ctx);
+                    } else {
                     hipLaunchKernelGGL(bdf::newton_rhs_kernel, gn, b256, 0, ctx->stream, f, psi, d, N, c, w.rhs_r, w.flags);
                     LAUNCH_OK(ctx);
                     if (int rc = radau_solve(ctx, w, false)) return rc;
@@ -2047,6 +2052,7 @@ int bdf_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_step
                             hipLaunchKernelGGL(radau::sum_partials_kernel, dim3(1), dim3(1), 0, ctx->stream, w.partial, nbk, w.out);
                             LAUNCH_OK(ctx);
                         }
+                    }
                     }
                     double ss;
                     int nonfinite;

@@ -100,6 +100,54 @@ __global__ void __launch_bounds__(1024) newton_update_kernel(const double* __res
     if (threadIdx.x == 0) out[blockIdx.x] = red[0];
 }
 
+// One Newton iteration's linear algebra in ONE launch for small systems (5 N <= PCR_FUSED_MAX; the real system only, so one workgroup
+// holds it all): right-hand side (newton_rhs_kernel) staged straight into LDS, every cyclic-reduction level (pcr_solve_all), then the
+// update and its norm (newton_update_kernel) - the same arithmetic in the same order, three launches less per iteration.
+__global__ void __launch_bounds__(radau::PCR_FUSED_THREADS) newton_fused_kernel(const double* __restrict__ f, const double* __restrict__ psi, int64_t N, double c,
+                                                                                  int nlevels, radau::PcrSystem<double> Sr, const double* __restrict__ scale,
+                                                                                  double* __restrict__ ynew, double* __restrict__ d, int32_t* __restrict__ flags,
+                                                                                  double* __restrict__ out)
+{
+    using namespace radau;
+    __shared__ double lds[2 * PCR_FUSED_MAX + PCR_FUSED_MAX];   // ping-pong right-hand sides + the solution
+    __shared__ double red[PCR_FUSED_THREADS];
+    const int n = (int)(NF * N);
+    for (int kk = threadIdx.x; kk < n; kk += PCR_FUSED_THREADS) {
+        const int64_t i = to_field_major(kk, N);
+        const double fi = f[i];
+        if (!isfinite(fi)) *flags = 1;
+        lds[kk] = (c * fi - psi[i]) - d[i];
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int level = 0; level < nlevels; level++) {
+        const double* b = lds + cur * PCR_FUSED_MAX;
+        double* o = lds + (cur ^ 1) * PCR_FUSED_MAX;
+        for (int k = threadIdx.x; k < n; k += PCR_FUSED_THREADS) pcr_solve_row<double>(N, k, level, nlevels, Sr, b, o);
+        __syncthreads();
+        cur ^= 1;
+    }
+    double* x = lds + 2 * PCR_FUSED_MAX;
+    for (int k = threadIdx.x; k < n; k += PCR_FUSED_THREADS) pcr_solve_row<double>(N, k, nlevels, nlevels, Sr, lds + cur * PCR_FUSED_MAX, x);
+    __syncthreads();
+    double ss = 0;
+    for (int kk = threadIdx.x; kk < n; kk += PCR_FUSED_THREADS) {   // (newton_update_kernel with one workgroup)
+        const int64_t i = to_field_major(kk, N);
+        const double dy = x[kk];
+        const double e = dy / scale[i];
+        ss += e * e;
+        ynew[i] += dy;
+        d[i] += dy;
+    }
+    red[threadIdx.x] = ss;
+    __syncthreads();
+    for (int s2 = 512; s2 > 0; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
 // out[block] = sum (coef v / (atol + rtol |yref|))^2   (the error norms of bdf.py:398-400, 428-436)
 __global__ void __launch_bounds__(1024) scaled_norm_kernel(const double* __restrict__ v, double coef, const double* __restrict__ yref, double rtol, double atol,
                                                            int64_t n, double* __restrict__ out)

@@ -121,3 +121,17 @@ def test_zero_copy_result_words_change_nothing(method):
     assert (a.status, a.nfev, a.njev, a.nlu, a.n_accepted) == (b.status, b.nfev, b.njev, b.nlu, b.n_accepted)
     assert np.array_equal(a.y_final, b.y_final)
     assert all(np.array_equal(x, y) for x, y in zip(a.t_events, b.t_events))
+
+
+def test_bdf_fused_newton_launch_is_bit_identical():
+    """Small systems (5 N <= 2048): right-hand side, every cyclic-reduction level, update and norm of a Newton iteration in ONE launch
+    (bdf::newton_fused_kernel) against the four separate kernels (option radau_fused_solve = 0): the same arithmetic in the same order."""
+    g, p, eq = _model("A")
+    out = []
+    for fused in (0, 1):
+        eq.set_option("radau_fused_solve", fused)
+        out.append(eq.integrate_bdf(g["y0"], tuple(g["t_span"]), float(g["first_step"]), float(g["rtol"]), float(g["atol"])))
+    eq.close()
+    a, b = out
+    assert (a.status, a.nfev, a.njev, a.nlu, a.n_accepted) == (b.status, b.nfev, b.njev, b.nlu, b.n_accepted)
+    assert np.array_equal(a.y_final, b.y_final)
