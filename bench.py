@@ -40,6 +40,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# fp64 vector issue ceiling: 256 CUs x 4 SIMDs, one wave64 fp64 VALU instruction per 4 cycles and SIMD, at the 2400 MHz maximum
+# clock of the same guide (= 78.6 TFLOP/s of fp64 FMA).  The chip holds 1.9 - 2.35 GHz under this load: the fraction is
+# against the spec clock, as the HBM fraction is against the spec bandwidth.
+VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 4.0
 BYTES_PER_POINT_STEP = 80.0    # 5 fields x 8 B read + 5 x 8 B written per grid-point-step
 MIN_TIMED_S = 0.05             # repeat the K-step block until this much has been timed
 MAX_REPS = 400
@@ -374,19 +378,39 @@ def main():
         # achieved = ALGORITHMIC bytes per launch / average launch duration = 80 B x grid-point-steps / HIP-event time
         # of the timed block on the launch stream (launches are back to back, so gaps count against the kernel)
         achieved = BYTES_PER_POINT_STEP * units / (ev_ms * 1e-3) / 1e9  # GB/s
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        # `bound` names what binds the kernel: the fused integrators advance several steps per pass over
+        # the state, draw a fraction of the algorithmic bytes from HBM and are limited by fp64 VALU issue.  achieved / peak /
+        # frac stay the task contract's figures - the EFFECTIVE rate of 80 algorithmic bytes per grid-point-step against the
+        # HBM roofline (north_star's "% of HBM roofline"); valu_issue_frac is the fraction of the roofline that does bind.
+        roof = {"bound": "fp64_valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None, "kernel": kernel, "algorithmic_bytes_per_grid_point_step": BYTES_PER_POINT_STEP,
-                "limiter": "fp64 VALU issue (the kernel advances several steps per pass over the state: measured HBM traffic is a "
-                           "fraction of the algorithmic bytes; see hbm_measured_gbs and DESIGN.md 5)",
                 "note": "achieved = algorithmic bytes (80 B x grid-point-steps of one launch) / launch duration (HIP events on the launch "
-                        "stream); it is an effective rate against the one-step-per-pass HBM roofline, NOT the HBM bandwidth the "
-                        "kernel draws - that is hbm_measured_gbs (PMC bytes per launch / launch duration)"}
-        pmc = None
-        for tag in ("r02", "r01"):
+                        "stream): an effective rate against the one-step-per-pass HBM roofline, NOT the bandwidth the kernel draws "
+                        "(hbm_measured_gbs: PMC bytes per launch / launch duration).  The kernel is bound by fp64 VALU issue: "
+                        "valu_issue_frac = VALU wave-instructions of the launch (SQ_INSTS_VALU of the committed counter pass: a "
+                        "property of code + input) / launch duration of THIS run / (1024 SIMDs x 2.4 GHz / 4 cycles)"}
+        pmc = sqc = None
+        for tag in ("r03", "r02", "r01"):
             f = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.json")
-            if os.path.exists(f):
+            if pmc is None and os.path.exists(f):
                 pmc = (tag, json.load(open(f)))
-                break
+            f = os.path.join(ROOT, "profiles", f"{tag}_pmc_sq_counters.json")
+            if sqc is None and os.path.exists(f):
+                sqc = (tag, json.load(open(f)))
+        # VALU issue fraction of the dominant kernel: instructions per grid-point-step from the counter pass of the same workload
+        # and size (profiles/<tag>_pmc_sq_counters.json, "valu_insts_per_grid_point_step"), time from this run
+        wl_key = {"rk4_single": "default" if N == (1 << 20) else ("n65536" if N == 65536 else None), "rk45_single": "rk45_single" if N == (1 << 20) else None,
+                  "sweep_rk45": "sweep_rk45", "sweep_rk4": "sweep_rk4"}.get(args.workload)
+        if args.no_reuse and wl_key == "default":
+            wl_key = "default_no_reuse"
+        if sqc and wl_key and args.variant < 0:
+            ks = sqc[1].get("workloads", {}).get(wl_key, {})
+            k = next((v for n, v in ks.items() if kernel in n and "valu_insts_per_grid_point_step" in v), None)
+            if k:
+                rate = k["valu_insts_per_grid_point_step"] * units / (ev_ms * 1e-3)
+                roof["valu_issue_frac"] = rate / VALU_PEAK_WAVE_INSTS_PER_S
+                roof["valu"] = {"wave_insts_per_grid_point_step": k["valu_insts_per_grid_point_step"], "wave_insts_per_s": rate,
+                                "peak_wave_insts_per_s": VALU_PEAK_WAVE_INSTS_PER_S, "source": f"profiles/{sqc[0]}_pmc_sq_counters.json ({wl_key})"}
         if pmc and args.workload == "rk4_single" and N == (1 << 20) and args.variant < 0:
             want = "rk4_stream_kernel<256, 1, 4" if kernel == "rk4_stream_kernel" else "rk4_fused_kernel<256, 1, 1, 4"
             k = next((v for n, v in pmc[1]["kernels"].items() if want in n), None)
@@ -418,6 +442,7 @@ def main():
         if not printed.acquire(blocking=False):
             return
         if rank == 0:
+            line["extras_timed_out"] = bool(timed_out)   # top level: a hung extra must not read as a clean run
             if timed_out:
                 extra["extras_timed_out_after_s"] = EXTRAS_DEADLINE_S
             if extra:
@@ -426,7 +451,10 @@ def main():
 
     def deadline():
         emit(timed_out=True)
-        os._exit(0)     # a hung collective cannot be unwound; the headline line is out
+        # a hung collective cannot be unwound: leave.  The headline line is out and valid (it was measured before the extras
+        # started), so the exit code stays 0 unless MARL_BENCH_TIMEOUT_RC asks otherwise (the rehearsal test sets it); the
+        # line itself says "extras_timed_out": true at top level
+        os._exit(int(os.environ.get("MARL_BENCH_TIMEOUT_RC", "0")))
 
     do_extras = args.workload == "rk4_single" and args.n is None and args.variant < 0 and not args.no_extras and not args.no_reuse
     if do_extras:
@@ -449,7 +477,13 @@ def main():
 
         def x_no_reuse():
             w, _, r = run_rk4_single(1 << 20, steps, warmup, args.layout, -1, no_reuse=True)
-            extra["rk4_N1048576_no_reuse"] = {"value": float(1 << 20) * steps * world / w, "unit": "grid-point-steps/s", "n_ranks": world,
+            v = float(1 << 20) * steps * world / w
+            if rank == 0:   # beside the headline's fraction, on the line the driver parses: the input dependence of the headline
+                line["roofline"]["frac_reuse_off"] = BYTES_PER_POINT_STEP * v / world / 1e9 / HBM_PEAK_GBS
+                line["roofline"]["frac_reuse_off_note"] = ("same kernel with transcendental reuse forced off (extra.rk4_N1048576_no_reuse; wall-clock based): "
+                                                           "the input-independent floor; `frac` needs a state smooth enough for the stage-to-stage expansions")
+            extra["rk4_N1048576_no_reuse"] = {"value": v, "unit": "grid-point-steps/s", "n_ranks": world,
+                                              "effective_frac_of_hbm_roofline_per_gpu": BYTES_PER_POINT_STEP * v / world / 1e9 / HBM_PEAK_GBS,
                                               "note": "same kernel, no evaluation may reuse the transcendentals of an earlier one (what a rough "
                                                       "state does wave by wave): the input-independent floor of the headline"}
 

@@ -178,7 +178,11 @@ int marl_slab_status(marl_ctx* ctx, marl_stats* stats);        /* synchronises *
  * rank (any transport); comm_init with world = 1 and id = NULL runs one slab with no communicator.
  * Sequence:  comm_init -> load -> exchange(0) -> rhs0 -> monitors(NULL) -> exchange(0) -> init_control(NULL, world, ...) -> run
  * -> store.  marl_slab_run enqueues  attempt -> reduce + pack -> all-gather -> unpack + control  `poll_interval` attempts at a
- * time and reads the status once per batch. */
+ * time (never more than the attempt budget has left) and reads the status once per batch.
+ * ncclCommInitRank is collective: marl_slab_comm_probe checks everything that is local (librccl loadable, entry points
+ * present) so that the host layer can agree on the transport BEFORE any rank enters it; comm_init rejects an id that
+ * marl_slab_comm_id cannot have produced (all zero) without touching RCCL. */
+int marl_slab_comm_probe(const char* rccl_path);
 int marl_slab_comm_id(const char* rccl_path, char id_out[128]);
 int marl_slab_comm_init(marl_ctx* ctx, const char* rccl_path, const char id[128], int rank, int world);
 int marl_slab_exchange(marl_ctx* ctx, int which);

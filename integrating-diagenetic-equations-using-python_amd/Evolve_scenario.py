@@ -10,9 +10,12 @@ reference (Evolve_scenario.py:19) and returns the same tuple
 * ``backend == "hip"`` and ``method == "Radau"`` (the reference's default, parameters.py:213): scipy's Radau IIA step
   logic restated natively, with the RHS, the finite-difference Jacobian (the reference's 27-diagonal pattern), the
   block-tridiagonal LU factorisations and every vector operation on the GPU via ``marl_integrate_radau`` - no scipy in the loop.
-* ``backend == "hip"`` and any other scipy method (BDF, LSODA, ...; or ``solver_parms["scipy_driver"] = True``):
-  scipy's ``solve_ivp`` drives, exactly as in the reference (:104-109), with the HIP RHS and HIP monitors
-  as callables.
+* ``backend == "hip"`` and ``method == "BDF"``: scipy's BDF step logic restated natively on the same Jacobian /
+  factorisation kernels via ``marl_integrate_bdf`` - no scipy in the loop either.
+* ``backend == "hip"`` and any other scipy method (RK23, DOP853, LSODA with the reference's ``lband = uband = 1``; or any
+  method with ``solver_parms["scipy_driver"] = True``): scipy's ``solve_ivp`` drives, exactly as in the reference
+  (:104-109), with the HIP RHS and HIP monitors as callables
+  (``test_every_other_method_of_the_reference_solver_runs_through_scipy_on_the_hip_rhs``).
 * other backends: rejected - this package has no CPU implementation.
 
 Results are stored like the reference's (:156-178) with the same dataset names, as ``.npz`` (always) and
@@ -58,7 +61,8 @@ def integrate_equations(solver_parms, tracker_parms, pde_parms, results_root="..
     t_eval = tracker_parms.get("t_eval")
     no_progress_updates = tracker_parms.get("no_progress_updates", 100_000)
     start = time.time()
-    if method == "RK45":
+    scipy_driver = bool(solver_parms.pop("scipy_driver", False))
+    if method == "RK45" and not scipy_driver:
         res = eq.integrate_rk45(y0, t_span, solver_parms["first_step"], solver_parms["rtol"], solver_parms["atol"],
                                 t_eval=t_eval)
         t_out, y_out, t_events = res.t, res.y, res.t_events
@@ -66,7 +70,7 @@ def integrate_equations(solver_parms, tracker_parms, pde_parms, results_root="..
         if status not in (0, -1):
             status = -1
         covered = Tstar * (t_span[1] if status == 0 else res.t_reached)
-    elif method in ("Radau", "BDF") and not solver_parms.get("scipy_driver", False):
+    elif method in ("Radau", "BDF") and not scipy_driver:
         # the reference's default: the whole implicit loop on the GPU (marl_integrate_radau).  The Jacobian pattern is the
         # reference's (parameters.py:150-199); when the caller's jac_sparsity has the matching shape its scipy column grouping
         # is used, otherwise a structured colouring - the Jacobian entries are the same either way.
@@ -85,7 +89,6 @@ def integrate_equations(solver_parms, tracker_parms, pde_parms, results_root="..
         covered = Tstar * (t_span[1] if status == 0 else res.t_reached)
     else:
         from scipy.integrate import solve_ivp
-        solver_parms.pop("scipy_driver", None)
         # the reference forwards every remaining Solver key to solve_ivp; keep only what the method takes
         drop = {"jac_sparsity"} if method == "LSODA" else {"lband", "uband"}
         if method not in ("Radau", "BDF", "LSODA"):

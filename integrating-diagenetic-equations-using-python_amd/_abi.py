@@ -79,6 +79,7 @@ PROTOTYPES = {
     "marl_slab_attempt": (_I, [_P, _P]),
     "marl_slab_control": (_I, [_P, _P, _L]),
     "marl_slab_status": (_I, [_P, C.POINTER(MarlStats)]),
+    "marl_slab_comm_probe": (_I, [C.c_char_p]),
     "marl_slab_comm_id": (_I, [C.c_char_p, C.c_char_p]),
     "marl_slab_comm_init": (_I, [_P, C.c_char_p, C.c_char_p, _I, _I]),
     "marl_slab_exchange": (_I, [_P, _I]),

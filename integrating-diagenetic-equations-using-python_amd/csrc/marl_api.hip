@@ -61,6 +61,7 @@ struct marl_ctx {
     double* dd_gathered = nullptr;
     double* dd_recs = nullptr;
     int dd_rank = 0, dd_world = 1;
+    int64_t dd_max_attempts = 0;   // the attempt budget given to marl_slab_init_control (marl_slab_run sizes its batches by it)
     void* rccl_lib = nullptr;
     void* rccl_comm = nullptr;
     int (*rccl_allgather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
@@ -763,6 +764,17 @@ static void ctrl_to_stats(const Rk45Ctrl& c, marl_stats* st)
     for (int e = 0; e < 7; e++) { st->event_value[e] = c.g[e]; st->n_events[e] = c.n_events[e]; }
 }
 
+// Attempts to enqueue before the next status read: `poll`, but never more than an attempt budget has left - once the
+// controller has stopped, every further attempt / reduce / control launch of the batch is a dispatch that does nothing
+// (cheap, but it is time, and it dilutes per-launch profile averages).  Pauses for t_eval samples and events still cut a
+// batch short; those are rare.
+static int64_t attempts_per_batch(int64_t poll, int64_t max_attempts, int64_t executed)
+{
+    if (max_attempts <= 0) return poll;
+    const int64_t left = max_attempts - executed;
+    return left < 1 ? 1 : (left < poll ? left : poll);
+}
+
 // The adaptive loop on device buffers buf[0..3] (`layout`), state already in buf[0].
 // small = true: the grid fits one workgroup -> the persistent sweep kernel runs all attempts on-chip
 // (state in buf[0], FIELD-MAJOR; (y_old, f_old) of a paused step in buf[1], buf[3]).
@@ -804,6 +816,7 @@ static int rk45_run(marl_ctx* ctx, int layout, bool small, double t0, double t1,
     }
     int64_t seen_events[7] = {0, 0, 0, 0, 0, 0, 0};
     Rk45Ctrl& hc = *ctx->hctrl;
+    int64_t executed = 0;   // attempts the device has finished, as of the last status read
     while (true) {
         if (small) {
             const int v = sv;  // SWEEP_DISPATCH switches on `v`
@@ -811,11 +824,13 @@ static int rk45_run(marl_ctx* ctx, int layout, bool small, double t0, double t1,
             SWEEP_DISPATCH(rk45_sweep_kernel, ctx->buf[0], ctx->dconsts, ctx->dctrl, ctx->N, ctx->buf[1], ctx->buf[3])
             LAUNCH_OK(ctx);
         } else {
-            for (int64_t i = 0; i < ctx->poll; i++)
+            const int64_t batch = attempts_per_batch(ctx->poll, max_attempts, executed);
+            for (int64_t i = 0; i < batch; i++)
                 if (int rc = launch_attempt(ctx, v, layout)) return rc;
         }
         HIP_OK(ctx, hipMemcpyAsync(ctx->hctrl, ctx->dctrl, sizeof(Rk45Ctrl), hipMemcpyDeviceToHost, ctx->stream));
         HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+        executed = hc.attempts - (hc.status == ST_RUNNING ? 1 : 0);   // (a running controller has already prepared the next one)
         if (hc.status == ST_RUNNING) continue;
         const bool stepped = hc.n_acc > 0;
         // event roots inside the last accepted step (ivp.py:673-694)
@@ -1148,6 +1163,7 @@ int marl_slab_init_control(marl_ctx* ctx, const double* recs_dev, int64_t nrec, 
     hipLaunchKernelGGL(rk45_init_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->dctrl, ctx->rec, t0, t1, first_step, clamp_rtol(rtol), atol,
                        (int64_t)NF * ctx->N, max_attempts, 0);
     LAUNCH_OK(ctx);
+    ctx->dd_max_attempts = max_attempts;
     return 0;
 }
 
@@ -1231,6 +1247,15 @@ int dd_allgather(marl_ctx* ctx, const double** gathered)
 
 extern "C" {
 
+int marl_slab_comm_probe(const char* rccl_path)
+{
+    void* lib = open_rccl(rccl_path);
+    if (!lib) return fail(nullptr, -2, "marl_slab_comm_probe: cannot load librccl (%s)", dlerror());
+    for (const char* sym : {"ncclGetUniqueId", "ncclCommInitRank", "ncclAllGather", "ncclCommDestroy"})
+        if (!dlsym(lib, sym)) return fail(nullptr, -2, "marl_slab_comm_probe: %s not found in librccl", sym);
+    return 0;
+}
+
 int marl_slab_comm_id(const char* rccl_path, char id_out[128])
 {
     if (!id_out) return -1;
@@ -1254,6 +1279,9 @@ int marl_slab_comm_init(marl_ctx* ctx, const char* rccl_path, const char id[128]
     ctx->dd_world = world;
     if (world > 1 || id) {   // (world == 1 with an id: a one-rank communicator - exercises the RCCL path on one GPU)
         if (!id) return fail(ctx, -1, "marl_slab_comm_init: a unique id is required for world > 1");
+        bool zero = true;
+        for (int i = 0; i < 128; i++) zero = zero && id[i] == 0;
+        if (zero) return fail(ctx, -1, "marl_slab_comm_init: the unique id is all zero (not made by marl_slab_comm_id / ncclGetUniqueId)");
         ctx->rccl_lib = open_rccl(rccl_path);
         if (!ctx->rccl_lib) return fail(ctx, -2, "marl_slab_comm_init: cannot load librccl (%s)", dlerror());
         auto init_rank = (int (*)(void**, int, NcclId, int))dlsym(ctx->rccl_lib, "ncclCommInitRank");
@@ -1300,8 +1328,11 @@ int marl_slab_run(marl_ctx* ctx, marl_stats* stats)
     const int64_t nb = rk45_blocks(ctx, v);
     if (int rc = ensure_part(ctx, (size_t)std::max<int64_t>(nb + kReduceGroups, 1024))) return rc;
     const int msg = dd_msg(ctx);
+    int64_t executed = 0;
     while (true) {
-        for (int64_t i = 0; i < ctx->poll; i++) {
+        // (every rank computes the same batch size: the budget and the status are the same everywhere)
+        const int64_t batch = attempts_per_batch(ctx->poll, ctx->dd_max_attempts, executed);
+        for (int64_t i = 0; i < batch; i++) {
             if (ctx->var_dphi) launch_attempt_t<256, 1, true>(ctx, nb, LAYOUT_FIELD_MAJOR); else launch_attempt_t<256, 1>(ctx, nb, LAYOUT_FIELD_MAJOR);
             LAUNCH_OK(ctx);
             int64_t nrec = nb;
@@ -1319,6 +1350,7 @@ int marl_slab_run(marl_ctx* ctx, marl_stats* stats)
         HIP_OK(ctx, hipMemcpyAsync(ctx->hctrl, ctx->dctrl, sizeof(Rk45Ctrl), hipMemcpyDeviceToHost, ctx->stream));
         HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->hctrl->status != ST_RUNNING) break;
+        executed = ctx->hctrl->attempts - 1;
     }
     ctrl_to_stats(*ctx->hctrl, stats);
     return 0;

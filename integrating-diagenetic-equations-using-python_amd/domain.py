@@ -34,6 +34,8 @@ def partition(N, world):
 class HipSlabEngine:
     """A rank's slab on its GPU (marl_ctx_create_slab and the marl_slab_* calls)."""
 
+    native_backends = ("nccl",)   # torch.distributed backends under which the library-side RCCL transport is attempted
+
     def __init__(self, pde_parms, N_global, begin, end, device, halo=HALO):
         import torch
         from .LHeureux_model import LMAHeureuxPorosityDiff  # noqa: F401  (packing helper below mirrors its ctor)
@@ -113,6 +115,10 @@ class HipSlabEngine:
         _abi.check(None, self.lib.marl_slab_comm_id(self.rccl_path(), buf), "marl_slab_comm_id")
         return buf.raw
 
+    def comm_probe(self):
+        """Local check that the RCCL entry points can be loaded - everything about comm_init that is NOT collective."""
+        _abi.check(None, self.lib.marl_slab_comm_probe(self.rccl_path()), "marl_slab_comm_probe")
+
     def comm_init(self, uid, rank, world):
         self._call("marl_slab_comm_init", self.rccl_path(), uid, rank, world)
 
@@ -180,29 +186,56 @@ class DomainDecomposedRK45:
         uid = None
         backend = dist.get_backend(group) if dist.is_initialized() else None
         want = os.environ.get("MARL_DD_TRANSPORT", "auto")          # auto | native | torch | rccl1 (one-rank communicator)
-        if isinstance(e, HipSlabEngine) and want != "torch" and (self.world == 1 or backend == "nccl"):
-            try:
-                if self.world > 1 or want == "rccl1":
-                    box = [e.comm_id() if self.rank == 0 else None]
-                    if self.world > 1:
-                        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        # Every rank walks through the SAME sequence of collectives whatever fails locally (a rank that skipped the broadcast and
+        # went on to the all-reduce would pair different collectives or hang the job): eligibility depends only on values that
+        # are equal on all ranks; failures are carried as data (uid None / ok 0) into the next collective, never as control flow
+        # around it.  ncclCommInitRank itself is collective - everything that can be checked locally (library loadable, symbols
+        # present: comm_probe) is agreed on BEFORE it is entered.
+        eligible = (getattr(e, "native_backends", None) is not None and want != "torch"
+                    and (self.world == 1 or backend in e.native_backends))
+        error = None
+        if eligible:
+            need_comm = self.world > 1 or want == "rccl1"
+            ok = 1
+            if need_comm:
+                if self.rank == 0:
+                    try:
+                        uid = e.comm_id()
+                    except _abi.MarlError as ex:
+                        error = ex
+                try:
+                    e.comm_probe()
+                except _abi.MarlError as ex:
+                    error, ok = ex, 0
+                if self.world > 1:
+                    box = [uid]
+                    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
                     uid = box[0]
-                e.comm_init(uid, self.rank, self.world)
-                self.native = True
-            except _abi.MarlError:
-                if want in ("native", "rccl1"):
-                    raise
-        if dist.is_initialized() and self.world > 1:   # every rank must take the same path
-            flag = e.torch.tensor([1 if self.native else 0], device=e.device if backend == "nccl" else "cpu") if isinstance(e, HipSlabEngine) else None
-            if flag is not None:
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-                self.native = bool(flag.item())
+                    ok = self._all_min(ok if uid is not None else 0, e, backend)
+                elif uid is None:
+                    ok = 0
+            if ok:
+                try:
+                    e.comm_init(uid, self.rank, self.world)
+                except _abi.MarlError as ex:
+                    error, ok = ex, 0
+            if self.world > 1:
+                ok = self._all_min(ok, e, backend)
+            self.native = bool(ok)
+            if not self.native and want in ("native", "rccl1"):
+                raise error if error is not None else _abi.MarlError(f"MARL_DD_TRANSPORT={want}: the library-side transport failed on another rank")
         self.transport = ("library loop, one slab (no communicator)" if self.native and uid is None else
                           "library loop, ncclAllGather (RCCL via the C ABI)" if self.native else
                           "none (one slab), host loop" if self.world == 1 else
                           f"host loop, torch.distributed.all_gather_into_tensor, backend {backend}")
 
     # -- communication ---------------------------------------------------------------------------
+    def _all_min(self, value, e, backend):
+        """MIN of one int over the group (every rank calls it at the same point of the transport set-up)."""
+        flag = e.new_tensor(1).fill_(float(value)) if backend == "nccl" else __import__("torch").tensor([float(value)], dtype=__import__("torch").float64)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)
+        return int(flag.item())
+
     def _exchange(self, which):
         """pack -> all-gather -> unpack; afterwards ``recs`` holds every rank's record in rank order."""
         self.engine.pack(which, self.send_lo, self.send_hi)
@@ -236,14 +269,18 @@ class DomainDecomposedRK45:
         self._exchange(0)            # f halos (FSAL vector) + the monitors record of y(t0)
         e.init_control(self.recs, self.world, float(t_span[0]), float(t_span[1]), float(first_step), float(rtol),
                        float(atol), int(max_attempts))
+        executed = 0
         while True:
-            for _ in range(self.poll):
+            # never more attempts per batch than the budget has left (further ones would be dispatches that do nothing)
+            batch = self.poll if max_attempts <= 0 else max(1, min(self.poll, int(max_attempts) - executed))
+            for _ in range(batch):
                 e.attempt(self.rec)
                 self._exchange(-1)
                 e.control(self.recs, self.world)
             st = e.status()
             if st.status != 1:
                 break
+            executed = int(st.n_accepted + st.n_rejected)
         e.store(y_owned)
         return st
 

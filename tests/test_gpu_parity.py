@@ -690,6 +690,36 @@ def test_scipy_driven_radau_with_hip_rhs():
     assert np.max(np.abs(last - gold)) < 1e-3      # the stub-hosted reference itself is within 7e-5 of this golden
 
 
+@pytest.mark.parametrize("method", ["RK23", "DOP853", "LSODA"])
+def test_every_other_method_of_the_reference_solver_runs_through_scipy_on_the_hip_rhs(oracle, method):
+    """The reference's Solver accepts ANY solve_ivp method (marlpde/parameters.py:205-219: LSODA with lband = uband = 1, an explicit
+    method via replace(Solver(), method=...)); here every method without a native time loop is driven by scipy on the HIP RHS and
+    the HIP monitors (Evolve_scenario.py, the solve_ivp branch, the reference's :100-109).  Checked against the SAME scipy call on
+    the oracle's RHS: statistics, the final state and the result tuple.  Short span: explicit methods are stability-limited."""
+    from dataclasses import asdict, replace
+    from scipy.integrate import solve_ivp
+    from marlpde_amd.Evolve_scenario import integrate_equations
+    from marlpde_amd.parameters import Solver, Tracker
+    N, t1 = 200, 2e-4
+    p = scenario("A", N)
+    solver = asdict(replace(Solver(), method=method, t_span=(0.0, t1)))
+    tracker = asdict(Tracker()) | {"t_eval": np.linspace(0.0, t1, 2)}
+    last, covered, depths, Xstar, folder = integrate_equations(solver, tracker, p, results_root=None, verbose=False)
+    assert covered == pytest.approx(p["Tstar"] * t1) and folder is None and Xstar == p["Xstar"] and depths.N == N
+    assert last.shape == (5, N) and np.all(np.isfinite(last))
+
+    P = oracle.params_from_dict(p)
+    y0 = np.stack([np.full(N, p[k]) for k in ("CAIni", "CCIni", "cCaIni", "cCO3Ini", "PhiIni")]).ravel()
+    extra = {"lband": 1, "uband": 1} if method == "LSODA" else {}
+    ref = solve_ivp(lambda t, y: oracle.rhs(P, N, y), (0.0, t1), y0, method=method, t_eval=tracker["t_eval"], first_step=1e-6,
+                    rtol=1e-3, atol=1e-3, events=[lambda t, y, e=e: oracle.events(P, N, y)[e] for e in range(7)], **extra)
+    assert ref.status == 0
+    # explicit methods: the two RHS differ by ~1e-15 relative and the controller saw-tooths at the stability limit (SURVEY 6:
+    # fun vs fun_numba under RK45 end 1.4e-10 apart); LSODA's Newton / order decisions amplify the same noise up to its tolerance
+    tol = 2e-3 if method == "LSODA" else 1e-7
+    assert np.max(np.abs(last - ref.y[:, -1].reshape(5, N))) <= tol, method
+
+
 # ---------------------------------------------------------------------------------------------------------
 # edge cases the reference's formulas cover but its own tests do not
 # ---------------------------------------------------------------------------------------------------------

@@ -146,3 +146,80 @@ def test_domain_decomposition_matches_single_grid(oracle, world):
     out = _spawn(_dd_worker, world, N, t1, h0, rtol, atol, 7)
     _, st2, *_ = oracle.rk45(oracle.params_from_dict(p), N, y0, 0.0, t1, h0, rtol, atol, max_attempts=7)
     assert {out[r][1][:3] for r in range(world)} == {(2, st2.n_accepted, st2.n_rejected)}
+
+
+# ---- transport set-up of the domain-decomposed driver: collectives must pair up whatever fails locally ----------------------
+def _dd_transport_worker(rank, world, N, t1, first_step, rtol, atol, fail_where, fail_rank):
+    from cpu_engines import OracleSlabEngine
+    from marlpde_amd._abi import MarlError
+    from marlpde_amd.domain import DomainDecomposedRK45, owned_slice
+
+    class Stub(OracleSlabEngine):
+        """Claims the library-side transport under gloo; one of its set-up calls fails on one rank."""
+        native_backends = ("gloo",)
+        calls = []
+
+        def _maybe_fail(self, where):
+            self.calls.append(where)
+            if fail_where == where and rank == fail_rank:
+                raise MarlError(f"{where} failed on rank {rank} (injected)")
+
+        def comm_id(self):
+            self._maybe_fail("comm_id")
+            return b"\x01" * 128
+
+        def comm_probe(self):
+            self._maybe_fail("comm_probe")
+
+        def comm_init(self, uid, r, w):
+            assert uid == b"\x01" * 128 and (r, w) == (rank, world)
+            self._maybe_fail("comm_init")
+
+        def run(self):
+            raise AssertionError("the library loop must not be entered after a failed set-up")
+
+    p = scenario("A", N)
+    y0 = synthetic_state(p, N, amplitude=0.05)
+    dd = DomainDecomposedRK45(p, N, engine_factory=lambda b, e: Stub(p, N, b, e, 6), poll=5)
+    y = torch.from_numpy(owned_slice(y0, N, dd.begin, dd.end))
+    st = dd.integrate(y, (0.0, t1), first_step, rtol, atol, 0)
+    return y.numpy(), (st.status, st.n_accepted, st.n_rejected), dd.native, dd.transport, list(Stub.calls)
+
+
+@pytest.mark.parametrize("fail_where,fail_rank", [("comm_id", 0), ("comm_probe", 1), ("comm_init", 1)])
+def test_domain_transport_setup_failure_on_one_rank_falls_back_everywhere(oracle, fail_where, fail_rank):
+    """when rank 0 cannot make the RCCL id (or one rank cannot load RCCL, or its comm_init fails) every rank must
+    still walk through the same collectives and end on the same transport - here: all fall back to the host loop over
+    torch.distributed, and the run equals the single-grid integration.  Before the fix rank 0 skipped the broadcast the other
+    ranks were waiting in."""
+    N = 40
+    p = scenario("A", N)
+    dx2 = ((p["max_depth"] / p["Xstar"]) / N) ** 2
+    t1, h0, rtol, atol = 12 * dx2, 0.4 * dx2, 1e-4, 1e-6
+    y0 = synthetic_state(p, N, amplitude=0.05)
+    yref, st, *_ = oracle.rk45(oracle.params_from_dict(p), N, y0, 0.0, t1, h0, rtol, atol)
+    out = _spawn(_dd_transport_worker, 2, N, t1, h0, rtol, atol, fail_where, fail_rank)
+    assert [out[r][2] for r in (0, 1)] == [False, False]
+    assert all("host loop" in out[r][3] for r in (0, 1))
+    assert {out[r][1] for r in (0, 1)} == {(0, st.n_accepted, st.n_rejected)}
+    got = np.concatenate([out[r][0].reshape(5, -1) for r in (0, 1)], axis=1)
+    assert np.max(np.abs(got - yref.reshape(5, N))) <= 1e-13
+    if fail_where == "comm_id":       # nobody may enter the (collective) comm_init without an id
+        assert all("comm_init" not in out[r][4] for r in (0, 1))
+    if fail_where == "comm_probe":    # agreed on before anyone enters comm_init
+        assert all("comm_init" not in out[r][4] for r in (0, 1))
+
+
+def test_slab_comm_entry_points_fail_fast_without_a_context_or_library():
+    """What can be said about the RCCL set-up without a GPU: the probe is local and returns (it never blocks), a missing
+    context is an error, not a crash."""
+    import ctypes as C
+    from marlpde_amd import _abi
+    lib = _abi.load()
+    assert lib.marl_slab_comm_init(None, None, b"\x00" * 128, 0, 2) == -1
+    rc = lib.marl_slab_comm_probe(b"/nonexistent/librccl.so")
+    assert rc in (0, -2)      # 0: the loader found a default librccl; -2: none - either way an answer, at once
+    if rc != 0:
+        assert b"librccl" in lib.marl_last_error(None)
+    buf = C.create_string_buffer(128)
+    assert lib.marl_slab_comm_id(None, None) == -1 and buf.raw == b"\x00" * 128

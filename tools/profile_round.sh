@@ -38,6 +38,7 @@ pmc default_FETCH_SIZE FETCH_SIZE -- --steps 400 --warmup 400
 pmc default_WRITE_SIZE WRITE_SIZE -- --steps 400 --warmup 400
 pmc default_SQ1 $SQ1 -- --steps 400 --warmup 400
 pmc default_SQ2 $SQ2 -- --steps 400 --warmup 400
+pmc default_no_reuse_SQ1 $SQ1 -- --steps 400 --warmup 400 --no-reuse
 pmc rk45_single_FETCH_SIZE FETCH_SIZE -- --workload rk45_single --steps 200
 pmc rk45_single_WRITE_SIZE WRITE_SIZE -- --workload rk45_single --steps 200
 pmc rk45_single_SQ1 $SQ1 -- --workload rk45_single --steps 200
