@@ -2160,7 +2160,7 @@ int bdf_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_step
                 if (factors[i] != factors[i]) { best = i; break; }   // np.argmax: the first NaN
             order += best - 1;
             const double sf = safety * factors[best];
-            const double factor = (sf != sf) ? sf : ((sf < MAX_FACTOR) ? sf : MAX_FACTOR);
+            const double factor = (sf < MAX_FACTOR) ? sf : MAX_FACTOR;   // python's min(MAX_FACTOR, x): a NaN x yields MAX_FACTOR (bdf.py:442)
             S_h_abs *= factor;
             if (int rc = bdf_change_D(ctx, D, n, order, factor)) return rc;
             n_equal_steps = 0;

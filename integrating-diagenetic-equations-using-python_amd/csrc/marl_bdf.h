@@ -112,13 +112,17 @@ __global__ void __launch_bounds__(radau::PCR_FUSED_THREADS) newton_fused_kernel(
     __shared__ double lds[2 * PCR_FUSED_MAX + PCR_FUSED_MAX];   // ping-pong right-hand sides + the solution
     __shared__ double red[PCR_FUSED_THREADS];
     const int n = (int)(NF * N);
+    int bad = 0;
     for (int kk = threadIdx.x; kk < n; kk += PCR_FUSED_THREADS) {
         const int64_t i = to_field_major(kk, N);
         const double fi = f[i];
-        if (!isfinite(fi)) *flags = 1;
+        bad |= !isfinite(fi);
         lds[kk] = (c * fi - psi[i]) - d[i];
     }
-    __syncthreads();
+    // The non-finite flag and out[0] may both live in host-coherent memory that the host POLLS (marl_api.hip radau_read): it waits
+    // for out[0] and then trusts the flag.  A workgroup barrier does not order stores of different waves to system memory, so the
+    // flag is folded through the barrier and written by the one thread that later writes out[0], with a system-scope fence between.
+    const int any_bad = __syncthreads_or(bad);
     int cur = 0;
     for (int level = 0; level < nlevels; level++) {
         const double* b = lds + cur * PCR_FUSED_MAX;
@@ -145,7 +149,13 @@ __global__ void __launch_bounds__(radau::PCR_FUSED_THREADS) newton_fused_kernel(
         if ((int)threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = red[0];
+    if (threadIdx.x == 0) {
+        if (any_bad) {
+            *flags = 1;
+            __threadfence_system();   // the flag is visible to the host before the word it waits for
+        }
+        out[0] = red[0];
+    }
 }
 
 // out[block] = sum (coef v / (atol + rtol |yref|))^2   (the error norms of bdf.py:398-400, 428-436)

@@ -536,6 +536,14 @@ rk4_stream_kernel(double* bufA, double* bufB, const DevConsts* __restrict__ cons
     SB sb(lds, 0, consts);   // tables once per workgroup (barrier inside)
     const unsigned total = levels * tiles;   // (host: < 2^31)
 
+#ifdef MARL_LAB_BROKEN_STREAM_LATCH   // tests/test_stream_isa.py only: the round-2 loop shape whose code the invariant checker must REJECT
+    if (threadIdx.x == 0) {
+        s_item = __hip_atomic_fetch_add(&queue[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - item_base;
+        s_abort = 0;
+    }
+    while (true) {
+        __syncthreads();
+#else
     while (true) {
         // (barrier 1: every wave has left the previous item - s_item / s_abort may be rewritten.  It also separates the
         // thread-0 block below from the one at the end of the loop body: without it the two are fused across the back-edge
@@ -549,6 +557,7 @@ rk4_stream_kernel(double* bufA, double* bufB, const DevConsts* __restrict__ cons
             s_abort = 0;
         }
         __syncthreads();
+#endif
         const unsigned item = s_item;
         if (item >= total) break;
         const unsigned level = item / tiles, tile = item - level * tiles;
@@ -592,6 +601,10 @@ rk4_stream_kernel(double* bufA, double* bufB, const DevConsts* __restrict__ cons
         __syncthreads();                 // ... and everybody else's (and everybody has read s_item, s_abort)
         if (threadIdx.x == 0) {
             __hip_atomic_store(&done[tile], level_base + level + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef MARL_LAB_BROKEN_STREAM_LATCH
+            s_item = __hip_atomic_fetch_add(&queue[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - item_base;   // the item grab in the loop latch
+            s_abort = 0;
+#endif
         }
     }
 }

@@ -1339,9 +1339,9 @@ int marl_oracle_bdf(const marl_params *p, int64_t N, double *y, double t0, doubl
                 if (factors[i] != factors[i]) { best = i; break; }
             order += best - 1;
             const double sf = safety * factors[best];
-            const double factor = (sf < RD_MAX_FACTOR) ? sf : RD_MAX_FACTOR; /* min(MAX_FACTOR, x): NaN stays NaN in python... */
-            S_h_abs *= (sf != sf) ? sf : factor;
-            bdf_change_D(D, n, order, (sf != sf) ? sf : factor);
+            const double factor = (sf < RD_MAX_FACTOR) ? sf : RD_MAX_FACTOR; /* python's min(MAX_FACTOR, x): x is returned only if x < MAX_FACTOR, so a NaN x yields MAX_FACTOR (bdf.py:442) */
+            S_h_abs *= factor;
+            bdf_change_D(D, n, order, factor);
             n_equal_steps = 0;
             have_lu = 0;
         }

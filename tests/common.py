@@ -45,3 +45,20 @@ def synthetic_state(p, N, amplitude=0.01, waves=8):
 def noisy_state(p, N, seed=0, sigma=0.05):
     y = np.stack([np.full(N, p[k]) for k in ("CAIni", "CCIni", "cCaIni", "cCO3Ini", "PhiIni")])
     return (y * (1.0 + sigma * np.random.default_rng(seed).standard_normal((5, N)))).ravel()
+
+
+def record_parity(kind, key, got, want, same):
+    """Append one line to the implicit-path parity report: which (case, grouping, solver) combinations took
+    EVERY decision scipy took.  Written to gpurun_out/implicit_parity_report.jsonl when that directory is writable (the GPU box
+    merges it back; a copy of a full run is committed as profiles/r03_implicit_parity_report.jsonl) and printed (pytest -rA)."""
+    import json
+    line = json.dumps({"solver": kind, "case": key, "got_nfev_njev_nlu_steps": list(map(int, got)), "scipy_nfev_njev_nlu_steps": list(map(int, want)),
+                       "every_decision_as_scipy": bool(same)})
+    print("PARITY", line)
+    out = os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "implicit_parity_report.jsonl"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass

@@ -19,9 +19,18 @@ import json
 import numpy as np
 import pytest
 
-from common import GOLDEN, scenario
+from common import GOLDEN, record_parity, scenario
 
 pytestmark = pytest.mark.gpu
+
+# (case, radau_solver) pairs that do NOT walk scipy's decision sequence, with the reason - every other combination must reproduce
+# scipy's nfev / njev / nlu / step count EXACTLY (a regression from "same" to "within 2 rtol" cannot pass silently).
+# Observed with the round-3 build (profiles/r03_implicit_parity_report.jsonl): Scenario A and the tight run are exact with BOTH linear
+# solvers and both column groupings; the Matlab case is exact with the default solver (cyclic reduction).
+KNOWN_DIVERGING = {
+    ("matlab", 1): "block Thomas (the radau_solver = 1 cross-check, not the default): one Newton iteration at a knife-edge convergence-rate test "
+                   "of solve_collocation_system takes one iteration more (393 evaluations for scipy's 390; same 19 Jacobians / 80 factorisations / 38 steps)",
+}
 
 STATE_TOL = 5e-6   # observed 1.1e-6 (Scenario A, T* = 13 190 yr, 41 steps); see the module docstring
 
@@ -64,10 +73,12 @@ def test_radau_reproduces_scipy_on_the_reference_rhs(oracle, name, groups, solve
     # every decision as scipy took it (observed: A + Thomas, matlab + PCR, the tight run with both): the states agree closely; one
     # Newton iteration more somewhere changes an error estimate, hence the following step sizes, hence the solution at the level
     # of the solver's own tolerance (rtol = atol = 1e-3 here) - as it does between any two correct Radau implementations
-    same = (res.nfev, res.njev, res.nlu, res.n_accepted) == (int(g["nfev"]), int(g["njev"]), int(g["nlu"]), len(g["step_times"]) - 1)
+    want = (int(g["nfev"]), int(g["njev"]), int(g["nlu"]), len(g["step_times"]) - 1)
+    same = (res.nfev, res.njev, res.nlu, res.n_accepted) == want
+    record_parity("radau", f"{name}|groups={groups}|radau_solver={solver}", (res.nfev, res.njev, res.nlu, res.n_accepted), want, same)
+    if (name, solver) not in KNOWN_DIVERGING:
+        assert same, ("this combination reproduced scipy's statistics exactly when the list of known divergences was written", name, groups, solver)
     tol = STATE_TOL if same else 2 * float(g["rtol"])
-    if name == "A_N64_tight":
-        assert same
     assert np.max(np.abs(res.y_final - g["y_final"])) <= tol
     assert np.array_equal(res.y[:, 0], g["y0"]) and np.max(np.abs(res.y[:, -1] - g["y_final"])) <= tol
     assert [len(e) for e in res.t_events] == list(g["n_events"])
