@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmarl_hip.so")
+# (MARL_HIP_LIBRARY: another BUILD of the same library - kernel-lab A/B runs on the GPU box; never a different implementation)
+LIB_PATH = os.environ.get("MARL_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "libmarl_hip.so")
 
 NFIELDS = 5
 NEVENTS = 7

@@ -821,7 +821,11 @@ static int rk45_run(marl_ctx* ctx, int layout, bool small, double t0, double t1,
         if (small) {
             const int v = sv;  // SWEEP_DISPATCH switches on `v`
             const dim3 grid(1);
-            SWEEP_DISPATCH(rk45_sweep_kernel, ctx->buf[0], ctx->dconsts, ctx->dctrl, ctx->N, ctx->buf[1], ctx->buf[3])
+            if (events_on) {   // pauses on monitor sign changes (root finding): the loop shape that decides with this step's events
+                SWEEP_DISPATCH(rk45_sweep_events_kernel, ctx->buf[0], ctx->dconsts, ctx->dctrl, ctx->N, ctx->buf[1], ctx->buf[3])
+            } else {
+                SWEEP_DISPATCH(rk45_sweep_kernel, ctx->buf[0], ctx->dconsts, ctx->dctrl, ctx->N, ctx->buf[1], ctx->buf[3])
+            }
             LAUNCH_OK(ctx);
         } else {
             const int64_t batch = attempts_per_batch(ctx->poll, max_attempts, executed);

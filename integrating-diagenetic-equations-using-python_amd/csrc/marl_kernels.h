@@ -47,6 +47,14 @@ struct Slab {
 
 __device__ __forceinline__ double nanmin(double a, double b) { return (a < b || a != a) ? a : b; }
 __device__ __forceinline__ double nanmax(double a, double b) { return (a > b || a != a) ? a : b; }
+// FINITE: the caller only uses the result when every input is finite (the monitors of an ACCEPTED Dormand-Prince attempt: a
+// non-finite y_new, f(y_new), U or W makes the error norm NaN and the attempt is rejected; its record is never read) - plain
+// v_min_f64 / v_max_f64 then (one instruction instead of the four of a NaN-propagating select; np.min / np.max agree with them
+// on finite values).
+template <bool FINITE = false>
+__device__ __forceinline__ double mon_min(double a, double b) { return FINITE ? __builtin_fmin(a, b) : nanmin(a, b); }
+template <bool FINITE = false>
+__device__ __forceinline__ double mon_max(double a, double b) { return FINITE ? __builtin_fmax(a, b) : nanmax(a, b); }
 
 // ---------------------------------------------------------------------------------------------
 // Per-block stencil engine
@@ -119,7 +127,9 @@ struct StencilBlock {
         for (int c = 0; c < CPT; c++) {
             point_local<CACHE ? MODE : TR_PLAIN, (CACHE && CACHE_LDS) ? WIN : 0, VD>(ys[c], (zone_mask >> c) & 1u, K, C, T, pl[c], aux[c], cache[CACHE ? c : 0], reuse_live[c]);
             // one cell at a time: interleaving the cells' evaluations doubles the live temporaries (spills at CPT >= 2)
+#ifndef MARL_LAB_INTERLEAVE_CELLS   // (kernel-lab switch: let the scheduler interleave the cells of a thread - ILP instead of registers)
             if constexpr (CPT > 1) __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         __syncthreads();
         const int tl = tid > 0 ? tid - 1 : 0;
@@ -162,12 +172,13 @@ struct StencilBlock {
 // for another purpose once it has arrived here (the stencil kernels pass their edge-exchange buffers).
 // The quantities are transposed through LDS so that each wave reduces whole quantities: NQ/waves butterfly
 // reductions per wave instead of NQ (a 64-lane butterfly of one double costs 12 ds_bpermute + the combines).
-template <int BLK, int NQ, int NMIN>
+// FINITE: the extrema without NaN propagation (mon_min); the sum q[0] is unaffected - a NaN error norm still rejects the attempt.
+template <int BLK, int NQ, int NMIN, bool FINITE = false>
 __device__ __forceinline__ void block_reduce(double (&q)[NQ], double* scratch)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NW = BLK / 64;
-    auto combine = [](int j, double a, double o) { return (j == 0) ? a + o : (j <= NMIN ? nanmin(a, o) : nanmax(a, o)); };
+    auto combine = [](int j, double a, double o) { return (j == 0) ? a + o : (j <= NMIN ? mon_min<FINITE>(a, o) : mon_max<FINITE>(a, o)); };
     if constexpr (NW > 1) {
         __syncthreads();
 #pragma unroll
@@ -313,15 +324,16 @@ __device__ __forceinline__ void monitors_init(double (&q)[NQ])
     q[5] = q[6] = q[7] = -__builtin_inf();
 }
 
+template <bool FINITE = false>   // (see mon_min)
 __device__ __forceinline__ void monitors_accumulate(double (&q)[NQ], const double (&u)[NF], double U, double W)
 {
-    q[1] = nanmin(nanmin(nanmin(nanmin(nanmin(q[1], u[0]), u[1]), u[2]), u[3]), u[4]);
-    q[2] = nanmin(q[2], u[0]);
-    q[3] = nanmin(q[3], u[1]);
-    q[4] = nanmin(q[4], U);
-    q[5] = nanmax(q[5], u[0] + u[1]);
-    q[6] = nanmax(q[6], u[4]);
-    q[7] = nanmax(q[7], W);
+    q[1] = mon_min<FINITE>(mon_min<FINITE>(mon_min<FINITE>(mon_min<FINITE>(mon_min<FINITE>(q[1], u[0]), u[1]), u[2]), u[3]), u[4]);
+    q[2] = mon_min<FINITE>(q[2], u[0]);
+    q[3] = mon_min<FINITE>(q[3], u[1]);
+    q[4] = mon_min<FINITE>(q[4], U);
+    q[5] = mon_max<FINITE>(q[5], u[0] + u[1]);
+    q[6] = mon_max<FINITE>(q[6], u[4]);
+    q[7] = mon_max<FINITE>(q[7], W);
 }
 
 template <int LAYOUT>
@@ -454,8 +466,12 @@ __device__ __forceinline__ void rk4_advance(SB& sb, double (&y)[CPT][NF], double
 
 // One cell per thread: 4 waves per SIMD (<= 128 VGPRs; 4 workgroups of 256 share the CU's 160 KB of LDS).
 // Variants with more cells per thread keep the compiler's own choice.
+#ifndef MARL_LAB_RK4_WAVES_MIN   // kernel-lab switch: occupancy window the register allocator aims at
+#define MARL_LAB_RK4_WAVES_MIN (CPT == 1 ? 4 : 1)
+#define MARL_LAB_RK4_WAVES_MAX 8
+#endif
 template <int BLK, int CPT, int LAYOUT, int NSTEPS, bool VD = false>
-__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(CPT == 1 ? 4 : 1, 8))) rk4_fused_kernel(const double* __restrict__ yin, double* __restrict__ yout,
+__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MARL_LAB_RK4_WAVES_MIN, MARL_LAB_RK4_WAVES_MAX))) rk4_fused_kernel(const double* __restrict__ yin, double* __restrict__ yout,
                                                         const DevConsts* __restrict__ consts, Slab S, double dt)
 {
 #ifdef MARL_LAB_CLOCK
@@ -671,12 +687,17 @@ __device__ __forceinline__ void rk45_prepare_attempt(Rk45Ctrl& c)
     c.attempts++;
 }
 
-// Bottom of _step_impl + the driver's per-step bookkeeping.  rec = {sum (err/scale)^2, monitors of y_new}.
-// T: the log / exp tables when the caller has them in LDS (the one-workgroup sweep kernel, where 1023 lanes wait for
-// this one): err^-0.2 is then exp(-0.2 log err) at a fifth of OCML pow's instructions, ~3 ulp instead of 1.
-__device__ __forceinline__ void rk45_finish_attempt(Rk45Ctrl& c, const double (&rec)[NQ], const Tables* T = nullptr)
+// Bottom of _step_impl + the driver's per-step bookkeeping, in three pieces (rk45_finish_attempt = all three in order):
+//   rk45_decide         error norm -> accept / reject and the step-size factor (rk.py:146-165)
+//   rk45_events         the seven monitors of an accepted step against those of the step before (ivp.py:149-151, :673-694)
+//   rk45_advance_status end of interval / pause, and the next attempt's step (rk.py:119-142)
+// The one-workgroup sweep kernel runs decide + advance_status in EVERY wave (replicated scalar work, no publish barrier) and the
+// event bookkeeping one barrier later, off the critical path.
+// T: the log / exp tables when the caller has them in LDS: err^-0.2 is then exp(-0.2 log err) at a fifth of OCML pow's
+// instructions, ~3 ulp instead of 1.
+__device__ __forceinline__ bool rk45_decide(Rk45Ctrl& c, double sumsq, const Tables* T = nullptr)
 {
-    const double err = sqrt(rec[0]) / sqrt((double)c.n_total);  // common.py:63-65
+    const double err = sqrt(sumsq) / sqrt((double)c.n_total);  // common.py:63-65
     c.err_norm = err;
     c.nfev += 6;
     double f;
@@ -693,36 +714,120 @@ __device__ __forceinline__ void rk45_finish_attempt(Rk45Ctrl& c, const double (&
         c.h_prev = c.h_try;
         c.t = c.t_new;
         c.cur ^= 1;
-        // monitors, in the reference's order (Evolve_scenario.py:107-109)
-        const double gn[7] = {rec[1], rec[2], rec[3], rec[5] - 1.0, rec[6] - 1.0, rec[4], rec[7]};
-        int fired = 0;
+        return true;
+    }
+    // rk.py:162-165; a NaN norm lands here with factor 0.2
+    c.h_abs *= (f > dp::MIN_FACTOR) ? f : dp::MIN_FACTOR;
+    c.accepted_last = 0;
+    c.rejected = 1;
+    c.n_rej++;
+    return false;
+}
+
+// The same decision from the MEAN square error (sum / n) for the replicated controller of the one-workgroup sweep kernel, where
+// every wave pays for these instructions: err < 1 <=> err^2 < 1, and 0.9 err^-0.2 = 0.9 exp(-0.1 log err^2) - no square roots, no
+// division (inv_n = 1 / n_total, formed once), always through the LDS tables.  c.err_norm holds err^2 until the kernel leaves
+// (rk45_lean_finish).  Against rk45_decide the factor differs in the last bits (as the table path does from OCML pow already).
+__device__ __forceinline__ bool rk45_decide_lean(Rk45Ctrl& c, double sumsq, double inv_n, const Tables& T)
+{
+    const double e2 = sumsq * inv_n;
+    c.err_norm = e2;
+    c.nfev += 6;
+    double f;
+    if (e2 > 1e-300 && e2 < 1e300) f = dp::SAFETY * fast_exp(-0.1 * fast_log(e2, T), T);
+    else f = dp::SAFETY * pow(sqrt(e2), -0.2);
+    if (e2 < 1.0) {
+        double factor = (e2 == 0.0) ? dp::MAX_FACTOR : ((f < dp::MAX_FACTOR) ? f : dp::MAX_FACTOR);
+        if (c.rejected && !(factor < 1.0)) factor = 1.0;
+        c.h_abs *= factor;
+        c.accepted_last = 1;
+        c.rejected = 0;
+        c.n_acc++;
+        c.t_old = c.t;
+        c.h_prev = c.h_try;
+        c.t = c.t_new;
+        c.cur ^= 1;
+        return true;
+    }
+    c.h_abs *= (f > dp::MIN_FACTOR) ? f : dp::MIN_FACTOR;
+    c.accepted_last = 0;
+    c.rejected = 1;
+    c.n_rej++;
+    return false;
+}
+
+// rk45_prepare_attempt with the minimum-step test (10 ulp(t)) behind a cheap sufficient condition: h_abs > |t| 2^-48 > 10 ulp(t)
+// holds on every attempt of a healthy run, and nextafter costs ~20 instructions in every wave
+__device__ __forceinline__ void rk45_prepare_attempt_lean(Rk45Ctrl& c)
+{
+    if (!(c.h_abs > fabs(c.t) * 0x1p-48) || c.t == 0.0) {   // (t = 0: nextafter gives the smallest subnormal)
+        rk45_prepare_attempt(c);
+        return;
+    }
+    if (c.max_attempts > 0 && c.attempts >= c.max_attempts) {
+        c.status = ST_BUDGET;
+        return;
+    }
+    double t_new = c.t + c.h_abs;
+    if (t_new - c.t_bound > 0.0) t_new = c.t_bound;
+    c.t_new = t_new;
+    c.h_try = t_new - c.t;
+    c.h_abs = fabs(c.h_try);
+    c.attempts++;
+}
+
+// Monitor e of the step just accepted ([c.t_old, c.t], size c.h_prev): gn against the stored c.g[e]; returns 1 on a sign change.
+__device__ __forceinline__ int rk45_event_one(Rk45Ctrl& c, int e, double gn)
+{
+    const double go = c.g[e];
+    int fired = 0;
+    const bool up = go <= 0.0 && gn >= 0.0, down = go >= 0.0 && gn <= 0.0;  // ivp.py:149-151
+    if (up || down) {
+        const double d = go - gn;
+        const double tc = (d != 0.0) ? c.t_old + c.h_prev * (go / d) : c.t;
+        if (c.n_events[e] == 0) c.ev_first[e] = tc;
+        c.ev_last[e] = tc;
+        c.n_events[e]++;
+        fired = 1;
+    }
+    c.g[e] = gn;
+    return fired;
+}
+
+// monitor e (the reference's order, Evolve_scenario.py:107-109) from a reduction record {sum, min y, min CA, min CC, min U, max CA+CC, max Phi, max W}
+__device__ __forceinline__ double rk45_monitor_of_record(const double* rec, int e)
+{
+    const int slot = (e < 3) ? e + 1 : (e == 3 ? 5 : (e == 4 ? 6 : (e == 5 ? 4 : 7)));
+    return (e == 3 || e == 4) ? rec[slot] - 1.0 : rec[slot];
+}
+
+__device__ __forceinline__ int rk45_events(Rk45Ctrl& c, const double (&rec)[NQ])
+{
+    int fired = 0;
 #pragma unroll
-        for (int e = 0; e < 7; e++) {
-            const double go = c.g[e];
-            const bool up = go <= 0.0 && gn[e] >= 0.0, down = go >= 0.0 && gn[e] <= 0.0;  // ivp.py:149-151
-            if (up || down) {
-                const double d = go - gn[e];
-                const double tc = (d != 0.0) ? c.t_old + c.h_prev * (go / d) : c.t;
-                if (c.n_events[e] == 0) c.ev_first[e] = tc;
-                c.ev_last[e] = tc;
-                c.n_events[e]++;
-                fired = 1;
-            }
-            c.g[e] = gn[e];
-        }
+    for (int e = 0; e < 7; e++) fired |= rk45_event_one(c, e, rk45_monitor_of_record(rec, e));
+    return fired;
+}
+
+__device__ __forceinline__ void rk45_advance_status(Rk45Ctrl& c, bool accepted, int fired)
+{
+    if (accepted) {
         if (c.t - c.t_bound >= 0.0) {  // base.py:203-204
             c.status = ST_DONE;
         } else if (c.t >= c.pause_t || (fired && c.pause_on_event)) {
             c.status = ST_PAUSED;
             c.event_fired = fired;
         }
-    } else {  // rk.py:162-165; a NaN norm lands here with factor 0.2
-        c.h_abs *= (f > dp::MIN_FACTOR) ? f : dp::MIN_FACTOR;
-        c.accepted_last = 0;
-        c.rejected = 1;
-        c.n_rej++;
     }
     if (c.status == ST_RUNNING) rk45_prepare_attempt(c);
+}
+
+// rec = {sum (err/scale)^2, monitors of y_new}.
+__device__ __forceinline__ void rk45_finish_attempt(Rk45Ctrl& c, const double (&rec)[NQ], const Tables* T = nullptr)
+{
+    const bool accepted = rk45_decide(c, rec[0], T);
+    const int fired = accepted ? rk45_events(c, rec) : 0;
+    rk45_advance_status(c, accepted, fired);
 }
 
 // rec0: monitors record of y(t0).  RungeKutta.__init__ (rk.py:94-102) + ivp.py:645.
@@ -927,10 +1032,10 @@ rk45_attempt_kernel(double* __restrict__ Y0, double* __restrict__ Y1,
                 fout[at<LAYOUT>(f, l, S.ld)] = k7[c][f];
                 q[0] += dp45_err2(esum[c][f], h, f < PARK ? pk[(c * NF + f) * BLK] : y[c][f], yn[c][f], rtol, atol);
             }
-            monitors_accumulate(q, yn[c], aux[c].U, aux[c].W);
+            monitors_accumulate<true>(q, yn[c], aux[c].U, aux[c].W);   // (the controller reads the extrema of ACCEPTED attempts only: all finite)
         }
     }
-    block_reduce<BLK, NQ, NQMIN>(q, lds);   // the edge-exchange buffers are free now
+    block_reduce<BLK, NQ, NQMIN, true>(q, lds);   // the edge-exchange buffers are free now
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int j = 0; j < NQ; j++) part[(int64_t)blockIdx.x * NQ + j] = q[j];
@@ -1145,13 +1250,56 @@ __global__ void __launch_bounds__(256) slab_copy_kernel(double* __restrict__ Y0,
 // ---------------------------------------------------------------------------------------------
 // (1024-thread workgroups cap a thread at 128 VGPRs, which this kernel overruns: 38 spilled VGPRs.  Parking the step's first state in
 // LDS, and a 6th-order reuse tier for coarse grids, were measured and dropped - profiles/r02_lab_sweep_experiments.log)
-template <int BLK, int CPT, bool VD = false>
-__global__ void __launch_bounds__(BLK) rk45_sweep_kernel(double* __restrict__ Y, const DevConsts* __restrict__ consts,
-                                                         Rk45Ctrl* __restrict__ ctrls, int64_t N,
-                                                         double* __restrict__ Yold, double* __restrict__ Fold)
+//
+// Two loop shapes, one arithmetic (dp45_attempt, the error norm, the monitors, rk45_decide / rk45_events / rk45_advance_status):
+//   FAST = false  the round-1/2 loop: 8-quantity block reduction (4 barriers), scipy's controller on ONE lane while 1023 wait,
+//                 2 more barriers to publish it.  Kept for single small runs that pause on a monitor sign change (root finding:
+//                 the decision to pause needs the events of THIS step).
+//   FAST = true   (round 3; sweeps, and single runs without event pauses) the step controller off the critical path: each wave
+//                 butterflies its own sum of squares, ONE barrier makes the 16 partial sums visible, and EVERY wave adds them in
+//                 wave order and runs decide + advance_status itself - replicated scalar work, but no single-lane section and no
+//                 publish barriers; the controller's scalars are pushed into SGPRs (readfirstlane) so the replication costs no
+//                 vector registers.  The seven monitors go through LDS columns written before that one barrier; waves 0..6 reduce
+//                 one quantity each after it, and lanes 0..6 of wave 0 do the event bookkeeping (rk45_event_one) one barrier
+//                 later - after the first evaluation of the NEXT attempt, whose exchange barrier orders it - or after the loop.
+//                 Per attempt: 7 barriers instead of 12 (profiles/r03_lab_sweep.log).
+__device__ __forceinline__ double to_sgpr(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ int32_t to_sgpr(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t to_sgpr(int64_t v)
+{
+    return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int32_t)((uint64_t)v >> 32)) << 32) |
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)v));
+}
+// the fields of the step controller that rk45_decide / rk45_advance_status / rk45_prepare_attempt read or write
+__device__ __forceinline__ void ctrl_to_sgpr(Rk45Ctrl& c)
+{
+    c.t = to_sgpr(c.t); c.h_abs = to_sgpr(c.h_abs); c.t_bound = to_sgpr(c.t_bound); c.h_try = to_sgpr(c.h_try); c.t_new = to_sgpr(c.t_new);
+    c.t_old = to_sgpr(c.t_old); c.h_prev = to_sgpr(c.h_prev); c.pause_t = to_sgpr(c.pause_t);
+    c.nfev = to_sgpr(c.nfev); c.n_acc = to_sgpr(c.n_acc); c.n_rej = to_sgpr(c.n_rej); c.attempts = to_sgpr(c.attempts);
+    c.max_attempts = to_sgpr(c.max_attempts); c.n_total = to_sgpr(c.n_total);
+    c.status = to_sgpr(c.status); c.cur = to_sgpr(c.cur); c.rejected = to_sgpr(c.rejected); c.accepted_last = to_sgpr(c.accepted_last);
+    c.pause_on_event = to_sgpr(c.pause_on_event);
+}
+
+#ifndef MARL_SWEEP_PARK
+#define MARL_SWEEP_PARK 2
+#endif
+template <int BLK, int CPT, bool VD, bool FAST>
+__device__ __forceinline__ void rk45_sweep_body(double* __restrict__ Y, const DevConsts* __restrict__ consts, Rk45Ctrl* __restrict__ ctrls, int64_t N,
+                                                double* __restrict__ Yold, double* __restrict__ Fold)
 {
     using SB = StencilBlock<BLK, CPT, false, VD>;
-    __shared__ double lds[SB::LDS_DOUBLES];
+    constexpr int NW = BLK / 64;
+    constexpr int NMON = NQ - 1;                                  // the seven monitor extrema (record slots 1..7)
+    constexpr int FAST_DOUBLES = FAST ? NMON * BLK + NW + NQ : 0; // monitor columns [slot][thread], per-wave sums, the reduced record
+    // PARK fields of the step's first state y live in the thread's LDS column instead of registers (dp45_attempt): the 1024-thread
+    // shape is capped at 128 VGPRs and every scratch reload in the stage loop stalls all 16 waves in front of their barrier
+    // (measured: 6.6 -> 21.7 reloads per attempt = -17 %); two columns are what the 160 KB of LDS still hold beside the monitor columns
+    constexpr int PARK = (FAST && BLK == 1024 && CPT == 1) ? MARL_SWEEP_PARK : 0;
+    __shared__ double lds[SB::LDS_DOUBLES + FAST_DOUBLES + PARK * CPT * BLK];
     __shared__ Rk45Ctrl sc;
     const DevConsts& C = consts[blockIdx.x];
     double* yg = Y + (int64_t)blockIdx.x * NF * N;
@@ -1161,55 +1309,158 @@ __global__ void __launch_bounds__(BLK) rk45_sweep_kernel(double* __restrict__ Y,
     if (threadIdx.x == 0) sc = ctrls[blockIdx.x];
     __syncthreads();
     if (sc.status != ST_RUNNING) return;
-    const double rtol = sc.rtol, atol = sc.atol;
+    const double rtol = FAST ? to_sgpr(sc.rtol) : sc.rtol, atol = FAST ? to_sgpr(sc.atol) : sc.atol;
 
     double y[CPT][NF], k1[CPT][NF], yn[CPT][NF], k7[CPT][NF], esum[CPT][NF];
     PointAux aux[CPT];
     load_cells<CPT, LAYOUT_FIELD_MAJOR>(yg, l0, S, C, y);
     sb.eval(y, k1, aux);  // f(t, y): RungeKutta.__init__ (first launch) or re-derived on resume
-#define MARL_Y(c, f) y[c][f]
+    double* pk = lds + SB::LDS_DOUBLES + FAST_DOUBLES + threadIdx.x;
+    if constexpr (PARK > 0) {
+#pragma unroll
+        for (int c = 0; c < CPT; c++)
+#pragma unroll
+            for (int f = 0; f < PARK; f++) pk[(c * NF + f) * BLK] = y[c][f];
+    }
+#define MARL_Y(c, f) ((f) < PARK ? pk[((c) * NF + (f)) * BLK] : y[c][f])
+#define MARL_KEEP_OLD_STEP()                                                                                               \
+    _Pragma("unroll") for (int c = 0; c < CPT; c++) {                                                                      \
+        if (l0 + c < N) {                                                                                                  \
+            _Pragma("unroll") for (int f = 0; f < NF; f++) {                                                               \
+                Yold[(int64_t)blockIdx.x * NF * N + at<LAYOUT_FIELD_MAJOR>(f, l0 + c, N)] = MARL_Y(c, f);                  \
+                Fold[(int64_t)blockIdx.x * NF * N + at<LAYOUT_FIELD_MAJOR>(f, l0 + c, N)] = k1[c][f];                      \
+            }                                                                                                              \
+        }                                                                                                                  \
+    }
 
-    while (true) {
-        const double h = sc.h_try;
-        dp45_attempt<BLK, CPT, false, SB>(sb, h, y, k1, yn, k7, esum, aux);
-        double q[NQ];
-        monitors_init(q);
+    if constexpr (!FAST) {
+        while (true) {
+            const double h = sc.h_try;
+            dp45_attempt<BLK, CPT, false, SB>(sb, h, y, k1, yn, k7, esum, aux);
+            double q[NQ];
+            monitors_init(q);
 #pragma unroll
-        for (int c = 0; c < CPT; c++) {
-            if (l0 + c < N) {
+            for (int c = 0; c < CPT; c++) {
+                if (l0 + c < N) {
 #pragma unroll
-                for (int f = 0; f < NF; f++) q[0] += dp45_err2(esum[c][f], h, MARL_Y(c, f), yn[c][f], rtol, atol);
-                monitors_accumulate(q, yn[c], aux[c].U, aux[c].W);
+                    for (int f = 0; f < NF; f++) q[0] += dp45_err2(esum[c][f], h, MARL_Y(c, f), yn[c][f], rtol, atol);
+                    monitors_accumulate(q, yn[c], aux[c].U, aux[c].W);
+                }
             }
+            block_reduce<BLK, NQ, NQMIN>(q, lds);   // the edge-exchange buffers are free now
+            if (threadIdx.x == 0) rk45_finish_attempt(sc, q, &sb.T);
+            __syncthreads();
+            const int status = sc.status;
+            if (sc.accepted_last) {
+                if (status != ST_RUNNING && Yold) {
+                    // keep (y_old, f_old) of the step just accepted: the host replays it for dense output
+                    MARL_KEEP_OLD_STEP()
+                }
+#pragma unroll
+                for (int c = 0; c < CPT; c++)
+#pragma unroll
+                    for (int f = 0; f < NF; f++) {
+                        y[c][f] = yn[c][f];
+                        k1[c][f] = k7[c][f];
+                    }
+            }
+            __syncthreads();  // everyone has read sc before thread 0 may touch it again
+            if (status != ST_RUNNING) break;
         }
-        block_reduce<BLK, NQ, NQMIN>(q, lds);   // the edge-exchange buffers are free now
-        if (threadIdx.x == 0) rk45_finish_attempt(sc, q, &sb.T);
-        __syncthreads();
-        const int status = sc.status;
-        if (sc.accepted_last) {
-            if (status != ST_RUNNING && Yold) {
-                // keep (y_old, f_old) of the step just accepted: the host replays it for dense output
+    } else {
+        double* mon = lds + SB::LDS_DOUBLES;         // [slot 1..7][thread]: never touched by the evaluations' edge exchange
+        double* wsum = mon + NMON * BLK;             // [wave]
+        double* rec = wsum + NW;                     // [NQ]: the reduced monitors of the last accepted step (slots 1..7)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        // the controller, replicated: every lane holds the same values; what lives across an attempt sits in SGPRs
+        // (tried: the controller in a double-buffered LDS block re-read after the barrier - fewer SGPRs, but the register
+        // allocator then spilled more vector registers: 21.7 instead of 6.6 - 15.7 scratch reloads per attempt, -17 %)
+        Rk45Ctrl c = sc;
+        ctrl_to_sgpr(c);
+        const double inv_n = to_sgpr(1.0 / (double)c.n_total);
+        bool events_pending = false;                 // an accepted step whose monitors (rec) have not been compared with sc.g yet
+        auto event_bookkeeping = [&]() {             // lanes 0..6 of wave 0: one monitor each; sc.t_old / sc.h_prev / sc.t describe that step
+            if (threadIdx.x < 7) rk45_event_one(sc, threadIdx.x, rk45_monitor_of_record(rec, threadIdx.x));
+        };
+        while (true) {
+            const double h = c.h_try;
+            // (the first evaluation's exchange barrier also orders the monitor reduction of the previous attempt before the
+            // event bookkeeping below; dp45_attempt is opaque, so the bookkeeping follows the whole attempt's evaluations -
+            // still before this attempt's own decision changes c.t_old / c.h_prev / c.t)
+            dp45_attempt<BLK, CPT, false, SB, PARK>(sb, h, y, k1, yn, k7, esum, aux, DenseWeights{}, pk);
+            if (events_pending) {                    // wave-uniform
+                event_bookkeeping();
+                events_pending = false;
+            }
+            double q[NQ];
+            monitors_init(q);
 #pragma unroll
-                for (int c = 0; c < CPT; c++) {
-                    if (l0 + c < N) {
+            for (int cc = 0; cc < CPT; cc++) {
+                if (l0 + cc < N) {
 #pragma unroll
-                        for (int f = 0; f < NF; f++) {
-                            Yold[(int64_t)blockIdx.x * NF * N + at<LAYOUT_FIELD_MAJOR>(f, l0 + c, N)] = MARL_Y(c, f);
-                            Fold[(int64_t)blockIdx.x * NF * N + at<LAYOUT_FIELD_MAJOR>(f, l0 + c, N)] = k1[c][f];
-                        }
+                    for (int f = 0; f < NF; f++) q[0] += dp45_err2(esum[cc][f], h, MARL_Y(cc, f), yn[cc][f], rtol, atol);
+                    monitors_accumulate<true>(q, yn[cc], aux[cc].U, aux[cc].W);   // (only read for accepted attempts: all finite)
+                }
+            }
+            double e2 = q[0];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) e2 += __shfl_xor(e2, off, 64);   // every lane: the wave's sum (same order in every lane pair)
+            if (lane == 0) wsum[wave] = e2;
+#pragma unroll
+            for (int j = 1; j < NQ; j++) mon[(j - 1) * BLK + threadIdx.x] = q[j];
+            __syncthreads();                         // the ONE barrier between the attempt and the decision
+            double sumsq = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) sumsq += wsum[w];                          // wave order: the same sum in every wave
+            sumsq = to_sgpr(sumsq);
+            const bool accepted = rk45_decide_lean(c, sumsq, inv_n, sb.T);
+            if (accepted) {
+                if (threadIdx.x == 0) { sc.t_old = c.t_old; sc.h_prev = c.h_prev; sc.t = c.t; }   // the step the pending events belong to
+                if (c.t - c.t_bound >= 0.0) c.status = ST_DONE;   // (rk45_advance_status without the event pause, which this loop shape does not have)
+                else if (c.t >= c.pause_t) c.status = ST_PAUSED;
+            }
+            if (c.status == ST_RUNNING) rk45_prepare_attempt_lean(c);
+            c.t = to_sgpr(c.t); c.h_abs = to_sgpr(c.h_abs); c.h_try = to_sgpr(c.h_try); c.t_new = to_sgpr(c.t_new);
+            const int status = c.status;
+            if (accepted) {
+                // monitors of y_new: wave w reduces record slot w + 1 (+ NW, ...) over the workgroup's columns
+#pragma unroll
+                for (int jj = 0; jj < (NMON + NW - 1) / NW; jj++) {
+                    const int j = wave + jj * NW + 1;   // wave-uniform
+                    if (j < NQ) {
+                        // (finite values: see monitors_accumulate<true>; a maximum is the negated minimum of the negated values)
+                        const double sgn = (j <= NQMIN) ? 1.0 : -1.0;
+                        double a = sgn * mon[(j - 1) * BLK + lane];
+#pragma unroll
+                        for (int i = 1; i < NW; i++) a = __builtin_fmin(a, sgn * mon[(j - 1) * BLK + lane + 64 * i]);
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) a = __builtin_fmin(a, __shfl_xor(a, off, 64));
+                        if (lane == 0) rec[j] = sgn * a;
                     }
                 }
-            }
-#pragma unroll
-            for (int c = 0; c < CPT; c++)
-#pragma unroll
-                for (int f = 0; f < NF; f++) {
-                    y[c][f] = yn[c][f];
-                    k1[c][f] = k7[c][f];
+                events_pending = true;
+                if (status != ST_RUNNING && Yold) {
+                    MARL_KEEP_OLD_STEP()
                 }
+#pragma unroll
+                for (int cc = 0; cc < CPT; cc++)
+#pragma unroll
+                    for (int f = 0; f < NF; f++) {
+                        if (f < PARK) pk[(cc * NF + f) * BLK] = yn[cc][f]; else y[cc][f] = yn[cc][f];
+                        k1[cc][f] = k7[cc][f];
+                    }
+            }
+            if (status != ST_RUNNING) break;
         }
-        __syncthreads();  // everyone has read sc before thread 0 may touch it again
-        if (status != ST_RUNNING) break;
+        __syncthreads();                             // the last accepted step's monitors are reduced
+        if (events_pending) event_bookkeeping();
+        __syncthreads();
+        if (threadIdx.x == 0) {                      // the replicated controller back into the record that leaves the kernel
+            sc.t = c.t; sc.h_abs = c.h_abs; sc.h_try = c.h_try; sc.t_new = c.t_new;
+            sc.err_norm = sqrt(c.err_norm);          // (rk45_decide_lean keeps the mean square)
+            sc.nfev = c.nfev; sc.n_acc = c.n_acc; sc.n_rej = c.n_rej; sc.attempts = c.attempts;
+            sc.status = c.status; sc.rejected = c.rejected; sc.accepted_last = c.accepted_last; sc.cur = c.cur;
+        }
     }
 #pragma unroll
     for (int c = 0; c < CPT; c++) {
@@ -1219,10 +1470,29 @@ __global__ void __launch_bounds__(BLK) rk45_sweep_kernel(double* __restrict__ Y,
         }
     }
 #undef MARL_Y
+#undef MARL_KEEP_OLD_STEP
     if (threadIdx.x == 0) {
         sc.cur = 0;
         ctrls[blockIdx.x] = sc;
     }
+}
+
+// sweeps and single small runs that never pause on a monitor sign change
+template <int BLK, int CPT, bool VD = false>
+__global__ void __launch_bounds__(BLK) rk45_sweep_kernel(double* __restrict__ Y, const DevConsts* __restrict__ consts,
+                                                         Rk45Ctrl* __restrict__ ctrls, int64_t N,
+                                                         double* __restrict__ Yold, double* __restrict__ Fold)
+{
+    rk45_sweep_body<BLK, CPT, VD, true>(Y, consts, ctrls, N, Yold, Fold);
+}
+
+// single small runs with event root finding (Rk45Ctrl.pause_on_event): the decision to pause needs this step's events
+template <int BLK, int CPT, bool VD = false>
+__global__ void __launch_bounds__(BLK) rk45_sweep_events_kernel(double* __restrict__ Y, const DevConsts* __restrict__ consts,
+                                                                Rk45Ctrl* __restrict__ ctrls, int64_t N,
+                                                                double* __restrict__ Yold, double* __restrict__ Fold)
+{
+    rk45_sweep_body<BLK, CPT, VD, false>(Y, consts, ctrls, N, Yold, Fold);
 }
 
 template <int BLK, int CPT, bool VD = false>
