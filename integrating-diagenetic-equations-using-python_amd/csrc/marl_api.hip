@@ -16,6 +16,7 @@
 #include "marl_kernels.h"
 #include "marl_radau.h"
 #include "marl_radau_batch.h"
+#include "marl_radau_wg.h"
 #include "marl_bdf.h"
 
 using namespace marl;
@@ -82,6 +83,7 @@ struct marl_ctx {
     int64_t implicit_zero_copy = 1;  // scalar results of the implicit drivers through polled host memory (0: copy + synchronise)
     int64_t radau_fused_solve = 1;   // small systems (5 N <= 2048): all PCR levels of a solve in one launch
     int64_t radau_solver = 0;   // 0: block parallel cyclic reduction (parallel over depth); 1: sequential block Thomas
+    int64_t radau_sweep_wg = 0; // 1: sweeps of small grids with one persistent workgroup per instance (marl_radau_wg.h; measured slower so far); 0: the launch-per-action cycle
     std::string err;
 };
 
@@ -324,6 +326,7 @@ int marl_set_option(marl_ctx* ctx, const char* name, int64_t value)
     else if (n == "poll_interval") ctx->poll = value > 0 ? value : 1;
     else if (n == "radau_solver") ctx->radau_solver = value ? 1 : 0;
     else if (n == "radau_fused_solve") ctx->radau_fused_solve = value ? 1 : 0;
+    else if (n == "radau_sweep_wg") ctx->radau_sweep_wg = value ? 1 : 0;
     else if (n == "implicit_zero_copy") ctx->implicit_zero_copy = value ? 1 : 0;
     else if (n == "rk4_stream") ctx->rk4_stream = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "rk4_stream_test_raise") ctx->sq_test_raise = value != 0;
@@ -2319,7 +2322,33 @@ extern "C" int marl_sweep_radau_dev(marl_ctx* ctx, double* y_dev, double t0, dou
         hipError_t e_ = hipGetLastError();                                                            \
         if (e_ != hipSuccess) { cleanup(); return fail(ctx, -100 - (int)e_, "kernel launch failed: %s", hipGetErrorString(e_)); } \
     } while (0)
-    for (int64_t cycle = 0;; cycle++) {
+    // Option radau_sweep_wg = 1 (small grids, 5 N <= PCR_FUSED_MAX): ONE persistent workgroup per instance runs the instance's whole
+    // integration (marl_radau_wg.h) - same step logic function and kernel bodies, no host in the loop.  Built and measured in round 3
+    // (profiles/r03_lab_radau_wg.log): NOT the default - block cyclic reduction on ONE compute unit costs 0.64 ms per factorisation
+    // (126 group calls of dependent L2 round trips), 35 ms per Scenario-A instance against 9.4 ms for the launch-per-action path that
+    // spreads a factorisation over 50 workgroups; it needs a work-efficient (block Thomas) factorisation inside the workgroup to pay.
+    const bool use_wg = ctx->radau_sweep_wg && n <= PCR_FUSED_MAX;
+    if (use_wg) {
+        if (!ctx->cus) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) { cleanup(); return fail(ctx, -3, "device properties unavailable"); }
+            ctx->cus = prop.multiProcessorCount;
+        }
+        WgWork ww{};
+        ww.y = w.y; ww.f = w.f; ww.fnew = w.fnew; ww.ynew = w.ynew; ww.err = w.err; ww.yerr = w.yerr; ww.yold = w.yold; ww.scale = w.scale; ww.tmp = w.tmp;
+        ww.Z = w.Z; ww.W = w.W; ww.F = w.F; ww.Q = w.Q; ww.YS = w.YS; ww.fac = w.fac; ww.h = w.h; ww.yscale = w.yscale; ww.maxdiff = w.maxdiff; ww.scl = w.scl;
+        ww.hnew = w.hnew; ww.Jraw = w.Jraw; ww.YP = w.YP; ww.FN = w.FN; ww.J = w.J; ww.rhs_r = w.rhs_r; ww.rhs_c = w.rhs_c; ww.small = w.small; ww.groups = w.groups;
+        ww.Sr = w.Sr; ww.Sc = w.Sc; ww.ng = w.ng; ww.nlevels = w.nlevels; ww.zs = zs;
+        unsigned* next = reinterpret_cast<unsigned*>(dcounts);     // (the work-list counters are not used on this path)
+        (void)hipMemsetAsync(next, 0, sizeof(unsigned), ctx->stream);
+        const dim3 grid((unsigned)std::min<int64_t>(B, (int64_t)ctx->cus));
+        if (ctx->var_dphi)
+            hipLaunchKernelGGL(radau_wg_kernel<true>, grid, dim3(WG_THREADS), 0, ctx->stream, dctl, B, N, ww, ctx->dconsts, atol, P, E3[0], E3[1], E3[2], next);
+        else
+            hipLaunchKernelGGL(radau_wg_kernel<false>, grid, dim3(WG_THREADS), 0, ctx->stream, dctl, B, N, ww, ctx->dconsts, atol, P, E3[0], E3[1], E3[2], next);
+        RB_OK();
+    }
+    for (int64_t cycle = 0; !use_wg; cycle++) {
         // the controllers advance every instance to its next piece of work and sort the instances into work lists; the host
         // reads the list lengths (one small copy + synchronisation per cycle) and launches each kind of work over its list only
         if (!zc_words || cycle == 0) (void)hipMemsetAsync(dcounts, 0, sizeof(int32_t) * L_COUNT, ctx->stream);   // (publish_counts_kernel zeroes them afterwards)

@@ -395,17 +395,28 @@ __device__ __forceinline__ T mm_elem(const T* A, const T* B, int r, int c)
     return acc;
 }
 
+// A cell's 25 lanes and their LDS stage belong to ONE 32-lane group, i.e. to one wave: the exchanges through the stage need no
+// workgroup barrier - a wave's LDS operations execute in program order, so a fence at wavefront scope (no instruction; it only
+// stops the compiler from moving the accesses) is the whole synchronisation.  (Round 3: the workgroup barriers that stood here
+// cost 0.38 us each in the 1024-thread one-workgroup-per-instance integrator - 19 per group call, 92 % of a factorisation.)
+__device__ __forceinline__ void group_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Gauss-Jordan inverse with partial pivoting; d = this lane's element of D (destroyed), returns its element of D^-1.
-// All 256 threads call it (barriers inside); lanes with e >= 25 idle.
+// Every lane of the group's wave calls it; lanes with e >= 25 idle.
 template <class T>
 __device__ __forceinline__ T gj_inverse_elem(T d, int e, int r, int c, bool act, PcrStage<T>& st)
 {
     T v = lift(r == c ? 1.0 : 0.0, d);
 #pragma unroll
     for (int k = 0; k < NF; k++) {
-        __syncthreads();
+        group_sync();
         if (act) { st.A[e] = d; st.B[e] = v; }
-        __syncthreads();
+        group_sync();
         if (act) {
             int p = k;
             double best = abs1(st.A[k * NF + k]);
@@ -431,11 +442,13 @@ __device__ __forceinline__ T gj_inverse_elem(T d, int e, int r, int c, bool act,
 }
 
 // level < 0: blocks of level 0 from J and their inverses; else one PCR level (stride s = 2^level)
+// i: the cell of this 32-lane group, e: the lane's index in the group (the launch kernels: 8 cells per 256-thread workgroup; the
+// one-workgroup-per-instance integrator of marl_radau_wg.h: 32 cells per pass of its 1024 threads).  Every thread of the
+// group's wave must call it together.
 template <class T>
-__device__ void pcr_factor_group(const double* __restrict__ J, int64_t N, int level, T mu, const PcrSystem<T>& S, PcrStage<T>& st, double jscale = 1.0)
+__device__ void pcr_factor_group(const double* __restrict__ J, int64_t N, int level, T mu, const PcrSystem<T>& S, PcrStage<T>& st, double jscale, int64_t i,
+                                 int e)
 {
-    const int g = threadIdx.x >> 5, e = threadIdx.x & 31;
-    const int64_t i = (int64_t)blockIdx.x * PCR_CELLS_PER_BLOCK + g;
     const bool act = e < 25 && i < N;
     const int r = act ? e / NF : 0, c = act ? e % NF : 0;
     const int64_t ic = (i < N) ? i : N - 1;   // idle groups shadow the last cell (uniform barriers, no stores)
@@ -464,24 +477,24 @@ __device__ void pcr_factor_group(const double* __restrict__ J, int64_t N, int le
     // lower side: alpha = -L D_{i-s}^-1;  D += alpha U_{i-s};  L' = alpha L_{i-s}
     const bool lo = ic - s >= 0;
     T al = zero, ln = zero;
-    __syncthreads();
+    group_sync();
     if (act && lo) { st.A[e] = Lc[i * 25 + e]; st.B[e] = Ic[(i - s) * 25 + e]; }
-    __syncthreads();
+    group_sync();
     if (act && lo) al = lift(-1.0, mu) * mm_elem<T>(st.A, st.B, r, c);
-    __syncthreads();
+    group_sync();
     if (act && lo) { st.A[e] = al; st.B[e] = Uc[(i - s) * 25 + e]; st.C[e] = Lc[(i - s) * 25 + e]; }
-    __syncthreads();
+    group_sync();
     if (act && lo) { d = d + mm_elem<T>(st.A, st.B, r, c); ln = mm_elem<T>(st.A, st.C, r, c); }
     // upper side: gamma = -U D_{i+s}^-1;  D += gamma L_{i+s};  U' = gamma U_{i+s}
     const bool hi = ic + s < N;
     T ga = zero, un = zero;
-    __syncthreads();
+    group_sync();
     if (act && hi) { st.A[e] = Uc[i * 25 + e]; st.B[e] = Ic[(i + s) * 25 + e]; }
-    __syncthreads();
+    group_sync();
     if (act && hi) ga = lift(-1.0, mu) * mm_elem<T>(st.A, st.B, r, c);
-    __syncthreads();
+    group_sync();
     if (act && hi) { st.A[e] = ga; st.B[e] = Lc[(i + s) * 25 + e]; st.C[e] = Uc[(i + s) * 25 + e]; }
-    __syncthreads();
+    group_sync();
     if (act && hi) { d = d + mm_elem<T>(st.A, st.B, r, c); un = mm_elem<T>(st.A, st.C, r, c); }
     if (act) {
         S.alpha[((int64_t)level * N + i) * 25 + e] = al;
@@ -502,9 +515,10 @@ __global__ void __launch_bounds__(256) pcr_factor_kernel(const double* __restric
     if (B.act) { const RadauCtl* c = ctl_of(B); mu_r = c->mu_r; mu_c = cplx{c->mu_c_re, c->mu_c_im}; }
     J = z_shift(J, B); Sr = z_shift_system(Sr, B); Sc = z_shift_system(Sc, B);
     __shared__ PcrStage<cplx> stage[PCR_CELLS_PER_BLOCK];   // (the real system uses the same bytes)
-    const int g = threadIdx.x >> 5;
-    if (blockIdx.y == 0) pcr_factor_group<double>(J, N, level, mu_r, Sr, *reinterpret_cast<PcrStage<double>*>(&stage[g]), jscale);
-    else pcr_factor_group<cplx>(J, N, level, mu_c, Sc, stage[g], jscale);
+    const int g = threadIdx.x >> 5, e = threadIdx.x & 31;
+    const int64_t i = (int64_t)blockIdx.x * PCR_CELLS_PER_BLOCK + g;
+    if (blockIdx.y == 0) pcr_factor_group<double>(J, N, level, mu_r, Sr, *reinterpret_cast<PcrStage<double>*>(&stage[g]), jscale, i, e);
+    else pcr_factor_group<cplx>(J, N, level, mu_c, Sc, stage[g], jscale, i, e);
 }
 
 template <class T>

@@ -32,20 +32,14 @@ __device__ __forceinline__ double predict_factor(double h_abs, double h_abs_old,
 // over every instance spent 2.4 ms dispatching ~320 000 workgroups that returned at once).
 enum : int { L_RHS1 = 0, L_ACCEPT, L_JAC, L_LU, L_NEWTON, L_ERR, L_RUNNING, L_COUNT };
 
-__global__ void __launch_bounds__(64) radau_control_kernel(RadauCtl* __restrict__ ctls, const double* __restrict__ rec, int64_t B, int64_t n,
-                                                           int32_t* __restrict__ counts, int32_t* __restrict__ lists)
+// One instance's step logic from where it stopped to its next action (c.action, c.pc).  g_now: the seven monitors of the instance's y.
+__device__ __forceinline__ void radau_control_step(RadauCtl& c, const double (&g_now)[7], int64_t n)
 {
-    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (b >= B) return;
-    RadauCtl c = ctls[b];
-    if (c.pc == PC_DONE) return;
     const double S6 = sqrt(6.0);
     const double C3[3] = {(4 - S6) / 10, (4 + S6) / 10, 1};
     const double MU_REAL = 3 + pow(3.0, 2.0 / 3) - pow(3.0, 1.0 / 3);
     const double MU_C_RE = 3 + 0.5 * (pow(3.0, 1.0 / 3) - pow(3.0, 2.0 / 3)), MU_C_IM = -0.5 * (pow(3.0, 5.0 / 6) + pow(3.0, 7.0 / 6));
     constexpr double MIN_FACTOR = 0.2, MAX_FACTOR = 10;
-    const double* r = rec + b * 8;
-    const double g_now[7] = {r[1], r[2], r[3], r[5] - 1.0, r[6] - 1.0, r[4], r[7]};   // record_to_events (marl_api.hip)
     c.action = 0;
     int pc = c.pc;
     // a small interpreter: `continue` = go on with the new pc in this cycle, `break` out of the loop = yield
@@ -205,6 +199,19 @@ __global__ void __launch_bounds__(64) radau_control_kernel(RadauCtl* __restrict_
         break;
     }
     c.pc = pc;
+}
+
+__global__ void __launch_bounds__(64) radau_control_kernel(RadauCtl* __restrict__ ctls, const double* __restrict__ rec, int64_t B, int64_t n,
+                                                           int32_t* __restrict__ counts, int32_t* __restrict__ lists)
+{
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    RadauCtl c = ctls[b];
+    if (c.pc == PC_DONE) return;
+    const double* r = rec + b * 8;
+    const double g_now[7] = {r[1], r[2], r[3], r[5] - 1.0, r[6] - 1.0, r[4], r[7]};   // record_to_events (marl_api.hip)
+    radau_control_step(c, g_now, n);
+    const int pc = c.pc;
     ctls[b] = c;
     if (pc != PC_DONE) atomicAdd(&counts[L_RUNNING], 1);
     auto push = [&](int which) { lists[(int64_t)which * B + atomicAdd(&counts[which], 1)] = (int32_t)b; };

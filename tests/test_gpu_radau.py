@@ -216,6 +216,42 @@ def test_radau_sweep_equals_instance_by_instance(torch_cuda_radau, oracle):
     np.testing.assert_allclose(got[0].reshape(5, N), gold, rtol=0.1, atol=0.01)
 
 
+def test_radau_sweep_wg_agrees_with_the_launch_path(torch_cuda_radau):
+    """Option radau_sweep_wg = 1: ONE persistent workgroup integrates an instance from start to end (marl_radau_wg.h; opt-in - measured
+    slower than the launch-per-action cycle so far).  Same step-logic function, restated kernel bodies: the two paths must
+    agree like two correct Radau runs - every instance reaches the end, statistics within 10 % (the complex multiply-adds of the
+    factorisation are contracted differently in the two contexts, and decisions at knife edges then fall either way), states within
+    the reference's own tolerance; on the short runs, where no decision has flipped yet, to 1e-9."""
+    torch = torch_cuda_radau
+    from dataclasses import asdict
+    from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
+    from marlpde_amd.parameters import Map_Scenario
+    for N, t1, budget in ((200, 1.0, 0), (64, 0.3, 0), (409, 1.0, 12)):      # the reference's grid; a small one; the largest the one-workgroup solve holds
+        base = asdict(Map_Scenario()) | {"N": N}
+        inst = [{"Phi0": 0.6, "PhiIni": 0.5, "PhiNR": 0.6}, {"Phi0": 0.5, "PhiIni": 0.5, "PhiNR": 0.5, "k3": 0.01, "k4": 0.01},
+                {"Phi0": 0.6, "PhiIni": 0.6, "PhiNR": 0.6}, {"Phi0": 0.65, "PhiIni": 0.5, "PhiNR": 0.5, "k3": 0.05, "k4": 0.05}]
+        y0 = np.stack([np.concatenate([np.full(N, (base | d)[k]) for k in ("CAIni", "CCIni", "cCaIni", "cCO3Ini", "PhiIni")]) for d in inst])
+        out = {}
+        for wg in (0, 1):
+            eq = LMAHeureuxPorosityDiff.from_scenario(base, device=0, instances=inst)
+            eq.use_stream(torch.cuda.current_stream().cuda_stream)
+            eq.set_option("radau_sweep_wg", wg)
+            yd = torch.from_numpy(y0).cuda()
+            res = eq.sweep_radau_device(yd.data_ptr(), (0.0, t1), 1e-6, 1e-3, 1e-3, max_attempts=budget)
+            out[wg] = (yd.cpu().numpy(), res)
+            eq.close()
+        print(N, [(r.nfev, r.njev, r.nlu, r.n_accepted) for r in out[0][1]], [(r.nfev, r.njev, r.nlu, r.n_accepted) for r in out[1][1]])
+        for b in range(len(inst)):
+            a, w = out[0][1][b], out[1][1][b]
+            assert a.status == w.status == (2 if budget else 0)
+            for x, y in ((a.nfev, w.nfev), (a.njev, w.njev), (a.nlu, w.nlu), (a.n_accepted, w.n_accepted)):
+                assert abs(x - y) <= max(6, 0.1 * x), (N, b, x, y)
+            if budget:
+                assert a.t_reached == pytest.approx(w.t_reached, rel=1e-9) and np.max(np.abs(out[0][0][b] - out[1][0][b])) <= 1e-9
+            else:
+                np.testing.assert_allclose(out[1][0][b], out[0][0][b], rtol=0.1, atol=0.01)
+
+
 def test_radau_sweep_of_512_scenarios_properties(torch_cuda_radau):
     """A sweep the size bench.py reports (512 scenarios over Phi0 x PhiIni x k3 = k4, N = 200, to T*): every instance reaches T* with
     finite fields (positive porosity and concentrations), its statistics are in the range single runs show, and a sample of instances agrees with the same scenario
