@@ -63,11 +63,31 @@ __device__ __forceinline__ double mon_max(double a, double b) { return FINITE ? 
 // are far outside the expansions' range).  The cache (marl_math.h, PointCache) also needs its LDS slots to fit
 // the 64 KB a workgroup may declare: wide variants (512 threads, several cells per thread) run without it.
 // VD: the time-varying porosity diffusion coefficient (marl_params.dPhi_variable), see marl_math.h.
+// A lane's neighbour values straight from the neighbouring LANES of its wave (gfx9 DPP wave shifts: two v_mov_b32_dpp per double,
+// VALU speed, no LDS, no barrier).  from_left: lane i receives lane i - 1's value; from_right: lane i + 1's.  Lane 0 / lane 63 receive
+// their own value back - WAVE_TILE windows make those two lanes halo cells whose results are never written.
+__device__ __forceinline__ double wave_from_left(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false));   // wave_shr:1
+}
+__device__ __forceinline__ double wave_from_right(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false));   // wave_shl:1
+}
+
 template <int BLK, int CPT, bool REUSE = true, bool VD = false>
 struct StencilBlock {
     static constexpr int WIN = BLK * CPT;
     static constexpr int NSIDE = (CPT == 1) ? 1 : 2;
-    static constexpr int EDGE_DOUBLES = 2 * NSIDE * NF * BLK;       // edges [parity][side][field][thread]
+    // WAVE_TILE (kernel lab only - tools/rk4_lab.hip -DLAB_BLK=64; no shipped kernel instantiates it): the window is ONE wave (64
+    // cells, one per lane): neighbours come from the wave's own lanes by DPP, the two edge lanes are halo - a stage has no LDS
+    // exchange and no barrier.  Built for BASELINE configs[1] (N = 65 536: one or two waves per SIMD), measured, NOT faster: 3.3 -
+    // 3.8 us per additional step at 1.3 - 2 waves per SIMD against 3.64 us for the shipped 256-thread / 16-step kernel - a lone wave
+    // of this instruction stream issues one VALU instruction per ~12 cycles with or without the exchange (profiles/r03_lab_n65536.log)
+    static constexpr bool WAVE_TILE = (BLK == 64 && CPT == 1);
+    static constexpr int EDGE_DOUBLES = WAVE_TILE ? 0 : 2 * NSIDE * NF * BLK;       // edges [parity][side][field][thread]
     static constexpr bool CACHE_LDS = PC_LDS_SLOTS > 0;
     static constexpr bool CACHE = REUSE && (EDGE_DOUBLES + TABLE_DOUBLES + PC_LDS_SLOTS * WIN) * 8 <= 60 * 1024;
     static constexpr int CACHE_DOUBLES = CACHE ? PC_LDS_SLOTS * WIN : 0;
@@ -116,6 +136,28 @@ struct StencilBlock {
     template <int MODE = TR_PLAIN>
     __device__ __forceinline__ void eval(const double (&ys)[CPT][NF], double (&k)[CPT][NF], PointAux (&aux)[CPT])
     {
+        if constexpr (WAVE_TILE) {
+            PointLocal pl;
+            point_local<CACHE ? MODE : TR_PLAIN, (CACHE && CACHE_LDS) ? WIN : 0, VD>(ys[0], zone_mask & 1u, K, C, T, pl, aux[0], cache[0], reuse_live[0]);
+            double um[NF], up[NF];
+#pragma unroll
+            for (int f = 0; f < NF; f++) um[f] = wave_from_left(ys[0][f]);
+            const bool need_right_solids = __builtin_amdgcn_ballot_w64(!pl.upw) != 0;
+#pragma unroll
+            for (int f = 0; f < NF; f++) up[f] = (f >= 2 || need_right_solids) ? wave_from_right(ys[0][f]) : 0.0;
+            if (__builtin_amdgcn_ballot_w64((first_mask | last_mask) & 1u) != 0) {   // physical boundaries: two cells of the whole grid
+                if (last_mask & 1u) {
+#pragma unroll
+                    for (int f = 0; f < NF; f++) up[f] = ghost_upper(f, ys[0][f], um[f]);
+                }
+                if (first_mask & 1u) {
+#pragma unroll
+                    for (int f = 0; f < NF; f++) um[f] = ghost_lower(C->bc[f], ys[0][f]);
+                }
+            }
+            point_rates<VD>(ys[0], um, up, K, T, pl, k[0], need_right_solids);
+            return;
+        }
         double* e = lds + parity * (NSIDE * NF * BLK);
 #pragma unroll
         for (int f = 0; f < NF; f++) {
