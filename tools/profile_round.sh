@@ -24,6 +24,10 @@ rocprofv3 --kernel-trace --stats -d "$out/stats_n65536" --output-format csv -- p
 for w in sweep_rk45 rk45_single sweep_rk4 dd_rk45; do
   rocprofv3 --kernel-trace --stats -d "$out/stats_$w" --output-format csv -- python3 bench.py --no-cpu-baseline --workload $w --steps 400 > "$out/stats_$w.log" 2>&1
 done
+# the implicit path (the reference's DEFAULT solver): kernel statistics of single Radau runs (N = 200 / 16 000 / 64 000), BDF and a sweep;
+# HBM counters of the cyclic-reduction kernels on the large grid (one counter per pass)
+rocprofv3 --kernel-trace --stats -d "$out/stats_radau_single" --output-format csv -- python3 tools/radau_profile.py single > "$out/stats_radau_single.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$out/stats_radau_bdf_sweep" --output-format csv -- python3 tools/radau_profile.py bdf sweep > "$out/stats_radau_bdf_sweep.log" 2>&1
 echo "kernel stats done"
 SQ1="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS"
 SQ2="SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY"
@@ -48,4 +52,8 @@ pmc sweep_rk45_SQ2 $SQ2 -- --workload sweep_rk45 --steps 200 --warmup 5
 pmc sweep_rk4_SQ1 $SQ1 -- --workload sweep_rk4 --steps 200 --warmup 5
 pmc n65536_SQ1 $SQ1 -- --n 65536 --steps 800
 pmc n65536_SQ2 $SQ2 -- --n 65536 --steps 800
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c -d "$out/pmc_radau_single_$c" --output-format csv -- python3 tools/radau_profile.py single > "$out/pmc_radau_single_$c.log" 2>&1
+done
+rocprofv3 --pmc $SQ1 -d "$out/pmc_radau_single_SQ1" --output-format csv -- python3 tools/radau_profile.py single > "$out/pmc_radau_single_SQ1.log" 2>&1
 echo "pmc done"

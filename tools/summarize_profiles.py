@@ -184,6 +184,49 @@ for wl in ("default", "default_no_reuse", "n65536", "rk45_single", "sweep_rk45",
         sq["workloads"][wl] = out
 json.dump(sq, open(os.path.join(dst, f"{tag}_pmc_sq_counters.json"), "w"), indent=1)
 
+# ---- the implicit path: per kernel of the single Radau runs (N = 200 / 16 000 / 64 000), HBM bytes and VALU instructions against time ----
+def totals(sub):
+    """kernel -> counter -> sum over ALL dispatches (these kernels have no no-op launches)"""
+    acc = defaultdict(lambda: defaultdict(float))
+    for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            acc[row["Kernel_Name"]][row["Counter_Name"]] += float(row["Counter_Value"])
+            acc[row["Kernel_Name"]]["_ns_" + row["Counter_Name"]] += int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+            acc[row["Kernel_Name"]]["_n_" + row["Counter_Name"]] += 1
+    return acc
+
+
+imp = {"command": "rocprofv3 --kernel-trace --stats | --pmc FETCH_SIZE | WRITE_SIZE | SQ set -- python3 tools/radau_profile.py single   (Scenario A to T* "
+                  "with marl_integrate_radau at N = 200, 16 000 and 64 000, one after another; tools/profile_round.sh)",
+       "units": "sums over every dispatch of the kernel in the run; durations from the kernel trace of the --stats pass; FETCH_SIZE doubled "
+                "(gfx950: it counts half of the bytes of streaming loads - calibrated on convert_kernel in the explicit passes); "
+                "hbm_gbs = bytes / kernel time; valu_issue_frac = VALU wave-instructions / kernel time / (1024 SIMDs x 2.4 GHz / 4)",
+       "kernels": {}}
+tr = glob.glob(os.path.join(src, "stats_radau_single", "**", "*kernel_trace.csv"), recursive=True)
+if tr:
+    dur, calls = defaultdict(int), defaultdict(int)
+    for r in csv.DictReader(open(tr[0])):
+        dur[r["Kernel_Name"]] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        calls[r["Kernel_Name"]] += 1
+    fe, wr, sq1 = totals("pmc_radau_single_FETCH_SIZE"), totals("pmc_radau_single_WRITE_SIZE"), totals("pmc_radau_single_SQ1")
+    total_ns = sum(dur.values())
+    for k in sorted(dur, key=lambda x: -dur[x]):
+        if "marl::" not in k:
+            continue
+        e = {"calls": calls[k], "total_us": dur[k] / 1e3, "avg_us": dur[k] / 1e3 / calls[k], "share_of_gpu_time": dur[k] / total_ns}
+        if k in fe and k in wr:
+            rd, wrb = fe[k]["FETCH_SIZE"] * 1024 * 2.0, wr[k]["WRITE_SIZE"] * 1024
+            e.update(hbm_read_bytes=rd, hbm_write_bytes=wrb, hbm_gbs=(rd + wrb) / dur[k], hbm_frac_of_8TBs=(rd + wrb) / dur[k] / 8000.0)
+        if k in sq1 and "SQ_INSTS_VALU" in sq1[k]:
+            e.update(valu_wave_insts=sq1[k]["SQ_INSTS_VALU"], valu_issue_frac=sq1[k]["SQ_INSTS_VALU"] / (dur[k] * 1e-9) / (256 * 4 * 2.4e9 / 4))
+        imp["kernels"][k.replace("void ", "")[:110]] = {a: (round(b, 4) if isinstance(b, float) else b) for a, b in e.items()}
+    json.dump(imp, open(os.path.join(dst, f"{tag}_implicit_kernels.json"), "w"), indent=1)
+for name in ("stats_radau_single.log", "stats_radau_bdf_sweep.log"):
+    f = os.path.join(src, name)
+    if os.path.exists(f):
+        keep = [ln for ln in open(f).read().splitlines() if ln.startswith(("radau", "bdf"))]
+        open(os.path.join(dst, f"{tag}_{name.replace('stats_', 'timing_')}"), "w").write("\n".join(keep) + "\n")
+
 # ---- kernel-trace statistics and bench lines -------------------------------------------------------------------------
 for d in glob.glob(os.path.join(src, "stats_*")):
     if not os.path.isdir(d):
