@@ -146,6 +146,13 @@ int marl_integrate_bdf(marl_ctx* ctx, double* y, double t0, double t1, double fi
  * monitor sign changes are counted in n_events, root times are not located in a sweep).  N <= 1638.  Synchronises. */
 int marl_sweep_radau_dev(marl_ctx* ctx, double* y_dev, double t0, double t1, double first_step, double rtol, double atol,
                          const int32_t* groups, int64_t max_attempts, marl_stats* stats);
+/* The same sweep with the monitors' ROOT TIMES located inside it, as solve_ivp returns them for every run (sol.t_events,
+ * marlpde/Evolve_scenario.py:118-145, 175-177; scipy ivp.py:673-694 with solve_event_equation :51-76): after an accepted step in
+ * which a monitor changed sign, the instance's device-side controller runs Brent's method on the step's dense output - one
+ * dense-output evaluation + monitors per function evaluation.  t_events: host array [instances][7][max_events]; entry k of
+ * monitor e of instance b is valid for k < stats[b].n_events[e], the rest is NaN; sign changes beyond max_events are counted only. */
+int marl_sweep_radau_events_dev(marl_ctx* ctx, double* y_dev, double t0, double t1, double first_step, double rtol, double atol,
+                                const int32_t* groups, int64_t max_attempts, double* t_events, int64_t max_events, marl_stats* stats);
 
 /* ---- 1-D domain decomposition of ONE large grid (BASELINE config 5; the reference never decomposes the depth
  * axis).  One process per GPU holds a slab [g_begin, g_end) of the N_global cells in a slab context; the host

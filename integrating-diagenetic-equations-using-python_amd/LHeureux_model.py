@@ -353,16 +353,23 @@ class LMAHeureuxPorosityDiff:
         self._check(rc, "marl_integrate_rk45_dev")
         return RK45Result(stats)
 
-    def sweep_radau_device(self, y_dev_ptr, t_span, first_step, rtol, atol, max_attempts=0, groups=None):
+    def sweep_radau_device(self, y_dev_ptr, t_span, first_step, rtol, atol, max_attempts=0, groups=None, events=False, max_events=64):
         """Every instance of the model integrated with the reference's default solver (scipy Radau semantics), all instances
         advanced together on the device (marl_sweep_radau_dev); device states [instances][5N] in place.  Returns one
-        :class:`RK45Result` per instance (statistics; event sign changes are counted, not located)."""
+        :class:`RK45Result` per instance (statistics).  ``events=True``: the monitors' root times are located inside the sweep
+        (marl_sweep_radau_events_dev) and returned as ``t_events`` - a list of 7 arrays per instance, what the reference prints and
+        stores for every run (Evolve_scenario.py:118-145, 175-177); otherwise sign changes are only counted."""
         grp = None if groups is None else np.ascontiguousarray(groups, dtype=np.int32)
         stats = (MarlStats * self.n_instances)()
-        rc = self._lib.marl_sweep_radau_dev(self._ctx, C.c_void_p(y_dev_ptr), float(t_span[0]), float(t_span[1]), float(first_step), float(rtol),
-                                            float(atol), _as_ptr(grp) if grp is not None else None, int(max_attempts), stats)
-        self._check(rc, "marl_sweep_radau_dev")
-        return [RK45Result(s) for s in stats]
+        args = (self._ctx, C.c_void_p(y_dev_ptr), float(t_span[0]), float(t_span[1]), float(first_step), float(rtol), float(atol),
+                _as_ptr(grp) if grp is not None else None, int(max_attempts))
+        if not events:
+            self._check(self._lib.marl_sweep_radau_dev(*args, stats), "marl_sweep_radau_dev")
+            return [RK45Result(s) for s in stats]
+        tev = np.full((self.n_instances, NEVENTS, int(max_events)), np.nan)
+        self._check(self._lib.marl_sweep_radau_events_dev(*args, _as_ptr(tev), int(max_events), stats), "marl_sweep_radau_events_dev")
+        return [RK45Result(s, t_events=[tev[b, e, :min(int(s.n_events[e]), int(max_events))].copy() for e in range(NEVENTS)])
+                for b, s in enumerate(stats)]
 
     def sweep_rk45_device(self, y_dev_ptr, t_span, first_step, rtol, atol, max_attempts=0):
         stats = (MarlStats * self.n_instances)()

@@ -69,6 +69,7 @@ PROTOTYPES = {
     "marl_integrate_radau": (_I, [_P, _P, _D, _D, _D, _D, _D, _P, _P, _L, _P, _P, _L, _L, C.POINTER(MarlStats)]),
     "marl_integrate_bdf": (_I, [_P, _P, _D, _D, _D, _D, _D, _P, _P, _L, _P, _P, _L, _L, C.POINTER(MarlStats)]),
     "marl_sweep_radau_dev": (_I, [_P, _P, _D, _D, _D, _D, _D, _P, _L, C.POINTER(MarlStats)]),
+    "marl_sweep_radau_events_dev": (_I, [_P, _P, _D, _D, _D, _D, _D, _P, _L, _P, _L, C.POINTER(MarlStats)]),
     "marl_ctx_create_slab": (_I, [C.POINTER(MarlParams), _L, _L, _L, _L, _I, C.POINTER(_P)]),
     "marl_slab_load": (_I, [_P, _P]),
     "marl_slab_store": (_I, [_P, _P]),

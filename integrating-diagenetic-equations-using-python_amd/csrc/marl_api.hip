@@ -2052,6 +2052,7 @@ int bdf_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_step
             hipLaunchKernelGGL(bdf::predict_kernel, gn, b256, 0, ctx->stream, D, n, order, gamma, alpha[order], rtol, atol, ypred, w.scale, psi, w.ynew, d);
             LAUNCH_OK(ctx);
             bool converged = false;
+            bool fused_err = false;   // the converged iteration's launch also left the local error sum (small systems, zero-copy words)
             const double c = h / alpha[order];
             bool first_pass = true;
             while (!converged) {
@@ -2076,8 +2077,11 @@ int bdf_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_step
                     if (int rc = launch_rhs(ctx, w.ynew, f, LAYOUT_FIELD_MAJOR)) return rc;
                     st->nfev++;
                     if (n <= radau::PCR_FUSED_MAX && ctx->radau_fused_solve) {   // right-hand side + every level + update + norm in one launch
+                        // (with the zero-copy result words: the step's local error norm rides along - bdf.py:398-400 - one launch and
+                        //  one wait less per step)
+                        fused_err = ctx->zc_on;
                         hipLaunchKernelGGL(bdf::newton_fused_kernel, dim3(1), dim3(radau::PCR_FUSED_THREADS), 0, ctx->stream, f, psi, N, c, w.nlevels, w.Sr, w.scale,
-                                           w.ynew, d, w.flags, w.out);
+                                           w.ynew, d, w.flags, w.out, error_const[order], rtol, atol, fused_err ? ctx->zc_d + 2 : (double*)nullptr);
                         LAUNCH_OK(ctx);
                     } else {
                     hipLaunchKernelGGL(bdf::newton_rhs_kernel, gn, b256, 0, ctx->stream, f, psi, d, N, c, w.rhs_r, w.flags);
@@ -2125,7 +2129,8 @@ int bdf_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_step
             }
             safety = 0.9 * (2 * NEWTON_MAXITER + 1) / (2 * NEWTON_MAXITER + n_iter);
             double ss;
-            if (int rc = bdf_scaled_sumsq(ctx, w, d, error_const[order], w.ynew, rtol, atol, &ss)) return rc;
+            if (fused_err) ss = const_cast<const volatile double*>(ctx->zc_h)[2];   // written before the word radau_read waited for
+            else if (int rc = bdf_scaled_sumsq(ctx, w, d, error_const[order], w.ynew, rtol, atol, &ss)) return rc;
             error_norm = std::sqrt(ss) / std::sqrt((double)n);
             if (error_norm > 1) {
                 const double sf = safety * std::pow(error_norm, -1.0 / (order + 1));
@@ -2252,10 +2257,22 @@ extern "C" int marl_integrate_bdf(marl_ctx* ctx, double* y, double t0, double t1
 }
 
 // ---- a sweep of Radau instances (marl_radau_batch.h) -------------------------------------------------------------------------
+extern "C" int marl_sweep_radau_events_dev(marl_ctx* ctx, double* y_dev, double t0, double t1, double first_step, double rtol, double atol,
+                                           const int32_t* groups, int64_t max_attempts, double* t_events, int64_t max_events, marl_stats* stats);
+
 extern "C" int marl_sweep_radau_dev(marl_ctx* ctx, double* y_dev, double t0, double t1, double first_step, double rtol, double atol,
                                     const int32_t* groups, int64_t max_attempts, marl_stats* stats)
 {
+    return marl_sweep_radau_events_dev(ctx, y_dev, t0, t1, first_step, rtol, atol, groups, max_attempts, nullptr, 0, stats);
+}
+
+// t_events (host, may be NULL): [instance][7][max_events] root times of the seven monitors, located inside the sweep as the single run
+// locates them (dense output of the accepted step + Brent, one A_DENSE action per function evaluation); entries beyond n_events are NaN.
+extern "C" int marl_sweep_radau_events_dev(marl_ctx* ctx, double* y_dev, double t0, double t1, double first_step, double rtol, double atol,
+                                           const int32_t* groups, int64_t max_attempts, double* t_events, int64_t max_events, marl_stats* stats)
+{
     if (!ctx || !y_dev || !stats) return ctx ? fail(ctx, -1, "marl_sweep_radau_dev: invalid argument") : -1;
+    const bool locate = t_events != nullptr && max_events > 0;
     if (ctx->halo > 0) return fail(ctx, -1, "marl_sweep_radau_dev: whole-grid context required");
     if (!(first_step > 0) || !(t1 >= t0)) return fail(ctx, -1, "radau: need first_step > 0 and t1 >= t0 (forward integration)");
     if (t1 > t0 && first_step > t1 - t0) return fail(ctx, -1, "radau: `first_step` exceeds bounds");
@@ -2277,7 +2294,14 @@ extern "C" int marl_sweep_radau_dev(marl_ctx* ctx, double* y_dev, double t0, dou
     HIP_OK(ctx, hipMalloc((void**)&drec, sizeof(double) * NQ * B));
     HIP_OK(ctx, hipMalloc((void**)&dcounts, sizeof(int32_t) * (size_t)(radau::L_COUNT * (B + 1))));
     int32_t* dlists = dcounts + radau::L_COUNT;
-    auto cleanup = [&]() { (void)hipFree(dctl); (void)hipFree(drec); (void)hipFree(dcounts); };
+    double *drec_dense = nullptr, *dtev = nullptr;   // event root finding: monitors of the dense-output states, the root times
+    if (locate) {
+        HIP_OK(ctx, hipMalloc((void**)&drec_dense, sizeof(double) * NQ * B));
+        HIP_OK(ctx, hipMalloc((void**)&dtev, sizeof(double) * (size_t)(7 * max_events) * B));
+        HIP_OK(ctx, hipMemsetAsync(drec_dense, 0, sizeof(double) * NQ * B, ctx->stream));
+        HIP_OK(ctx, hipMemsetAsync(dtev, 0xff, sizeof(double) * (size_t)(7 * max_events) * B, ctx->stream));   // (all bits set: NaN)
+    }
+    auto cleanup = [&]() { (void)hipFree(dctl); (void)hipFree(drec); (void)hipFree(dcounts); if (drec_dense) (void)hipFree(drec_dense); if (dtev) (void)hipFree(dtev); };
     std::vector<RadauCtl> hctl((size_t)B);
     for (auto& c : hctl) {
         memset(&c, 0, sizeof c);
@@ -2285,6 +2309,7 @@ extern "C" int marl_sweep_radau_dev(marl_ctx* ctx, double* y_dev, double t0, dou
         c.newton_tol = std::fmax(10 * radau::EPS / rtol, std::fmin(0.03, std::sqrt(rtol)));
         c.t = t0; c.S_h_abs = first_step; c.S_h_abs_old = -1; c.S_err_old = -1;
         c.pc = radau::PC_INIT; c.status = 1;
+        c.locate_events = locate ? 1 : 0; c.max_events = max_events;
     }
     if (hipMemcpyAsync(dctl, hctl.data(), sizeof(RadauCtl) * B, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { cleanup(); return fail(ctx, -3, "copy failed"); }
     if (hipMemcpy2DAsync(w.y, (size_t)zs, y_dev, n * sizeof(double), n * sizeof(double), (size_t)B, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
@@ -2327,7 +2352,7 @@ extern "C" int marl_sweep_radau_dev(marl_ctx* ctx, double* y_dev, double t0, dou
     // (profiles/r03_lab_radau_wg.log): NOT the default - block cyclic reduction on ONE compute unit costs 0.64 ms per factorisation
     // (126 group calls of dependent L2 round trips), 35 ms per Scenario-A instance against 9.4 ms for the launch-per-action path that
     // spreads a factorisation over 50 workgroups; it needs a work-efficient (block Thomas) factorisation inside the workgroup to pay.
-    const bool use_wg = ctx->radau_sweep_wg && n <= PCR_FUSED_MAX;
+    const bool use_wg = ctx->radau_sweep_wg && n <= PCR_FUSED_MAX && !locate;   // (the one-workgroup path counts sign changes only)
     if (use_wg) {
         if (!ctx->cus) {
             hipDeviceProp_t prop;
@@ -2352,7 +2377,7 @@ extern "C" int marl_sweep_radau_dev(marl_ctx* ctx, double* y_dev, double t0, dou
         // the controllers advance every instance to its next piece of work and sort the instances into work lists; the host
         // reads the list lengths (one small copy + synchronisation per cycle) and launches each kind of work over its list only
         if (!zc_words || cycle == 0) (void)hipMemsetAsync(dcounts, 0, sizeof(int32_t) * L_COUNT, ctx->stream);   // (publish_counts_kernel zeroes them afterwards)
-        hipLaunchKernelGGL(radau_control_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, ctx->stream, dctl, drec, B, n, dcounts, dlists);
+        hipLaunchKernelGGL(radau_control_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, ctx->stream, dctl, drec, B, n, dcounts, dlists, drec_dense, dtev);
         RB_OK();
         if (zc_words) {   // the list lengths through polled host memory
             hipLaunchKernelGGL(publish_counts_kernel, dim3(1), dim3(1), 0, ctx->stream, dcounts, reinterpret_cast<int32_t*>(ctx->zc_d + 16), (int32_t)(cycle + 1));
@@ -2373,7 +2398,15 @@ extern "C" int marl_sweep_radau_dev(marl_ctx* ctx, double* y_dev, double t0, dou
         }
         if (hcounts[L_RUNNING] == 0) break;
         const unsigned nR = (unsigned)hcounts[L_RHS1], nA = (unsigned)hcounts[L_ACCEPT], nJ = (unsigned)hcounts[L_JAC], nL = (unsigned)hcounts[L_LU],
-                       nN = (unsigned)hcounts[L_NEWTON], nE = (unsigned)hcounts[L_ERR];
+                       nN = (unsigned)hcounts[L_NEWTON], nE = (unsigned)hcounts[L_ERR], nD = (unsigned)hcounts[L_DENSE];
+        if (nD) {   // event root finding: the dense output of the accepted step at the abscissa Brent asks for, and that state's monitors
+            hipLaunchKernelGGL(dense_eval_batch_kernel, dim3(gx, 1, nD), b256, 0, ctx->stream, w.Q, w.yold, n, w.tmp, Z(L_DENSE));
+            RB_OK();
+            hipLaunchKernelGGL(monitors_kernel<LAYOUT_FIELD_MAJOR>, dim3((unsigned)nbm, (unsigned)B), b256, 0, ctx->stream, w.tmp, ctx->dconsts, ctx->slab, zs / 8, ctx->part);
+            RB_OK();
+            hipLaunchKernelGGL(reduce_records_kernel, dim3((unsigned)B), b256, 0, ctx->stream, ctx->part, nbm, drec_dense);
+            RB_OK();
+        }
         if (nR) {   // a single state -> its derivative: y -> f (start), y + err -> tmp (second error estimate), y_new -> f_new (accepted step)
             if (ctx->var_dphi)
                 hipLaunchKernelGGL((rhs_pick_kernel<LAYOUT_FIELD_MAJOR, true>), dim3(gc, 1, nR), b256, 0, ctx->stream, w.y, w.f, w.yerr, w.tmp, w.ynew, w.fnew, ctx->dconsts,
@@ -2464,6 +2497,8 @@ extern "C" int marl_sweep_radau_dev(marl_ctx* ctx, double* y_dev, double t0, dou
     if (hipMemcpy2DAsync(y_dev, n * sizeof(double), w.y, (size_t)zs, n * sizeof(double), (size_t)B, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
         rc_out = fail(ctx, -3, "state copy failed");
     if (rc_out == 0 && hipMemcpyAsync(hctl.data(), dctl, sizeof(RadauCtl) * B, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc_out = fail(ctx, -3, "copy failed");
+    if (rc_out == 0 && locate && hipMemcpyAsync(t_events, dtev, sizeof(double) * (size_t)(7 * max_events) * B, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        rc_out = fail(ctx, -3, "copy failed");
     if (rc_out == 0 && hipStreamSynchronize(ctx->stream) != hipSuccess) rc_out = fail(ctx, -3, "synchronize failed");
     if (rc_out == 0)
         for (int64_t b = 0; b < B; b++) {

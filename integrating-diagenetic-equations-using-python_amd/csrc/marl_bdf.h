@@ -106,7 +106,8 @@ __global__ void __launch_bounds__(1024) newton_update_kernel(const double* __res
 __global__ void __launch_bounds__(radau::PCR_FUSED_THREADS) newton_fused_kernel(const double* __restrict__ f, const double* __restrict__ psi, int64_t N, double c,
                                                                                   int nlevels, radau::PcrSystem<double> Sr, const double* __restrict__ scale,
                                                                                   double* __restrict__ ynew, double* __restrict__ d, int32_t* __restrict__ flags,
-                                                                                  double* __restrict__ out)
+                                                                                  double* __restrict__ out, double err_coef = 0.0, double rtol = 0.0, double atol = 0.0,
+                                                                                  double* __restrict__ err_out = nullptr)
 {
     using namespace radau;
     __shared__ double lds[2 * PCR_FUSED_MAX + PCR_FUSED_MAX];   // ping-pong right-hand sides + the solution
@@ -149,12 +150,29 @@ __global__ void __launch_bounds__(radau::PCR_FUSED_THREADS) newton_fused_kernel(
         if ((int)threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        if (any_bad) {
-            *flags = 1;
-            __threadfence_system();   // the flag is visible to the host before the word it waits for
+    const double dy_ss = red[0];
+    // err_out: the local error norm this iteration's state WOULD have if the iteration turns out to be the converged one
+    // (bdf.py:398-400: error = error_const[order] d, scale = atol + rtol |y_new|) - the same terms, thread mapping and reduction tree
+    // as scaled_norm_kernel with one workgroup (bit-identical), so that the host needs neither a launch nor a wait for it
+    if (err_out) {
+        __syncthreads();   // every thread's d / ynew updates are visible; red[] is free again
+        double es = 0;
+        for (int64_t i = threadIdx.x; i < n; i += PCR_FUSED_THREADS) {
+            const double e = err_coef * d[i] / (atol + rtol * fabs(ynew[i]));
+            es += e * e;
         }
-        out[0] = red[0];
+        red[threadIdx.x] = es;
+        __syncthreads();
+        for (int s2 = 512; s2 > 0; s2 >>= 1) {
+            if ((int)threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (any_bad) *flags = 1;
+        if (err_out) *err_out = red[0];
+        __threadfence_system();   // the flag and the error sum are visible to the host before the word it waits for
+        out[0] = dy_ss;
     }
 }
 

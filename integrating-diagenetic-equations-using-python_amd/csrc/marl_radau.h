@@ -55,7 +55,7 @@ __device__ inline cplx lift(double a, cplx) { return {a, 0.0}; }
 // Batched sweeps of Radau instances (marl_radau_batch.h): every instance follows its own control flow, advanced one ACTION per
 // cycle by a device-side controller; the kernels below serve the single-instance driver (ctl == NULL, scalar arguments) and the
 // batched one (blockIdx.z = instance; per-instance scalars from ctl[z]; ZBatch masks out instances that need something else).
-enum : int32_t { A_RHS_Y = 1, A_JAC = 2, A_LU = 4, A_NEWTON = 8, A_ERR = 16, A_ACCEPT = 32, A_ERR2 = 64 };
+enum : int32_t { A_RHS_Y = 1, A_JAC = 2, A_LU = 4, A_NEWTON = 8, A_ERR = 16, A_ACCEPT = 32, A_ERR2 = 64, A_DENSE = 128 };
 struct RadauCtl {
     // set once
     double t_bound, rtol, atol, newton_tol;
@@ -76,6 +76,12 @@ struct RadauCtl {
     // results the kernels leave for the controller
     double sumsq;                    // sum of squares of the last norm kernel
     int32_t nonfinite, pad;
+    // event root finding inside a sweep (round 3; ivp.py:673-694 + solve_event_equation :51-76, Brent as in scipy's brentq): a resumable
+    // state machine - every function evaluation is one A_DENSE action (dense output at dense_x, monitors of that state)
+    int32_t locate_events, ev_pending, br_e, br_phase, br_iter, pad2;   // ev_pending: bit e = monitor e changed sign in the step just accepted
+    int64_t max_events;
+    double dense_x;                  // (t - sol_t_old) / sol_h of the state the A_DENSE kernels evaluate
+    double br_a, br_b, br_fa, xpre, xcur, xblk, fpre, fcur, fblk, spre, scur;
 };
 __device__ __forceinline__ const RadauCtl* ctl_of(const ZBatch& B)
 {

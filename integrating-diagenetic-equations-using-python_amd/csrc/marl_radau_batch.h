@@ -15,7 +15,8 @@
 namespace marl {
 namespace radau {
 
-enum : int32_t { PC_INIT = 0, PC_GOT_F0, PC_STEP, PC_ATTEMPT, PC_NEWTON_START, PC_NEWTON_LU_DONE, PC_NEWTON_ITER, PC_ERR_DONE, PC_ACCEPTED, PC_ACCEPTED_JAC_DONE, PC_DONE };
+enum : int32_t { PC_INIT = 0, PC_GOT_F0, PC_STEP, PC_ATTEMPT, PC_NEWTON_START, PC_NEWTON_LU_DONE, PC_NEWTON_ITER, PC_ERR_DONE, PC_ACCEPTED, PC_ACCEPTED_JAC_DONE, PC_DONE,
+                 PC_EVENTS, PC_BRENT };
 constexpr int NEWTON_MAXITER = 6;
 
 __device__ __forceinline__ double predict_factor(double h_abs, double h_abs_old, double error_norm, double error_norm_old)   // radau.py:133-173
@@ -30,10 +31,37 @@ __device__ __forceinline__ double predict_factor(double h_abs, double h_abs_old,
 // Work lists: the controller appends each instance to the list of every kernel group that serves its action; counts[L_*] are read by
 // the host, which sizes the launches by them (masked-out workgroups are not free: at 512 instances a cycle that launched every kernel
 // over every instance spent 2.4 ms dispatching ~320 000 workgroups that returned at once).
-enum : int { L_RHS1 = 0, L_ACCEPT, L_JAC, L_LU, L_NEWTON, L_ERR, L_RUNNING, L_COUNT };
+enum : int { L_RHS1 = 0, L_ACCEPT, L_JAC, L_LU, L_NEWTON, L_ERR, L_RUNNING, L_DENSE, L_COUNT };
 
 // One instance's step logic from where it stopped to its next action (c.action, c.pc).  g_now: the seven monitors of the instance's y.
-__device__ __forceinline__ void radau_control_step(RadauCtl& c, const double (&g_now)[7], int64_t n)
+// One pass of Brent's method (scipy.optimize.brentq as solve_event_equation calls it: xtol = rtol = 4 eps, at most 100 iterations)
+// from the top of its loop to the next function evaluation.  Returns true when the root is final (c.xcur); false: evaluate at c.xcur.
+__device__ __forceinline__ bool brent_advance(RadauCtl& c)
+{
+    const double xtol = 4 * EPS, rtol = xtol;
+    if (c.fpre != 0 && c.fcur != 0 && ((c.fpre < 0) != (c.fcur < 0))) { c.xblk = c.xpre; c.fblk = c.fpre; c.spre = c.scur = c.xcur - c.xpre; }
+    if (fabs(c.fblk) < fabs(c.fcur)) { c.xpre = c.xcur; c.xcur = c.xblk; c.xblk = c.xpre; c.fpre = c.fcur; c.fcur = c.fblk; c.fblk = c.fpre; }
+    const double delta = (xtol + rtol * fabs(c.xcur)) / 2, sbis = (c.xblk - c.xcur) / 2;
+    if (c.fcur == 0 || fabs(sbis) < delta) return true;
+    if (fabs(c.spre) > delta && fabs(c.fcur) < fabs(c.fpre)) {
+        double stry;
+        if (c.xpre == c.xblk) stry = -c.fcur * (c.xcur - c.xpre) / (c.fcur - c.fpre);
+        else {
+            const double dpre = (c.fpre - c.fcur) / (c.xpre - c.xcur), dblk = (c.fblk - c.fcur) / (c.xblk - c.xcur);
+            stry = -c.fcur * (c.fblk * dblk - c.fpre * dpre) / (dblk * dpre * (c.fblk - c.fpre));
+        }
+        const double lim = fmin(fabs(c.spre), 3 * fabs(sbis) - delta);
+        if (2 * fabs(stry) < lim) { c.spre = c.scur; c.scur = stry; }
+        else { c.spre = sbis; c.scur = sbis; }
+    } else { c.spre = sbis; c.scur = sbis; }
+    c.xpre = c.xcur; c.fpre = c.fcur;
+    if (fabs(c.scur) > delta) c.xcur += c.scur; else c.xcur += (sbis > 0 ? delta : -delta);
+    return false;
+}
+
+// g_dense: the seven monitors of the dense-output state the last A_DENSE action evaluated (event root finding); t_events: this
+// instance's root times [7][max_events] (NULL: sign changes are only counted).
+__device__ __forceinline__ void radau_control_step(RadauCtl& c, const double (&g_now)[7], int64_t n, const double* g_dense = nullptr, double* t_events = nullptr)
 {
     const double S6 = sqrt(6.0);
     const double C3[3] = {(4 - S6) / 10, (4 + S6) / 10, 1};
@@ -187,13 +215,68 @@ __device__ __forceinline__ void radau_control_step(RadauCtl& c, const double (&g
             c.t = c.t_new;
             c.sol_h = c.t - c.sol_t_old;
             c.have_sol = 1;
-            for (int e = 0; e < 7; e++) {        // non-terminal events, both directions (ivp.py:131-156); counts only in a sweep
+            c.ev_pending = 0;
+            for (int e = 0; e < 7; e++) {        // non-terminal events, both directions (ivp.py:131-156)
                 const bool up = c.g[e] <= 0 && g_now[e] >= 0, down = c.g[e] >= 0 && g_now[e] <= 0;
-                if (up || down) c.n_events[e]++;
+                if (up || down) {
+                    if (c.locate_events && t_events && c.n_events[e] < c.max_events) c.ev_pending |= 1 << e;   // located below; the count moves with the root
+                    else c.n_events[e]++;
+                }
                 c.g[e] = g_now[e];
             }
-            if (c.t - c.t_bound >= 0) { c.status = 0; pc = PC_DONE; break; }
-            pc = PC_STEP;
+            pc = PC_EVENTS;
+            continue;
+        }
+        if (pc == PC_EVENTS) {                   // the next monitor whose root in (sol_t_old, t] is still to be located (ivp.py:686-694)
+            if (c.ev_pending == 0) {
+                if (c.t - c.t_bound >= 0) { c.status = 0; pc = PC_DONE; break; }
+                pc = PC_STEP;
+                continue;
+            }
+            int e = 0;
+            while (!((c.ev_pending >> e) & 1)) e++;
+            c.br_e = e; c.br_phase = 0; c.br_iter = 0;
+            c.br_a = c.sol_t_old; c.br_b = c.t;
+            c.dense_x = 0.0;                     // f(a): the dense output at t_old
+            c.action = A_DENSE; pc = PC_BRENT;
+            break;
+        }
+        if (pc == PC_BRENT) {                    // the value of monitor br_e at the abscissa asked for
+            const double val = g_dense[c.br_e];
+            bool done = false;
+            double root = 0;
+            if (c.br_phase == 0) {
+                c.br_fa = val;
+                c.br_phase = 1;
+                c.dense_x = 1.0;                 // f(b): the dense output at t
+                c.action = A_DENSE;
+                break;
+            }
+            if (c.br_phase == 1) {
+                const double fa = c.br_fa, fb = val;
+                if (fa == 0) { done = true; root = c.br_a; }
+                else if (fb == 0) { done = true; root = c.br_b; }
+                else {
+                    c.xpre = c.br_a; c.xcur = c.br_b; c.fpre = fa; c.fcur = fb; c.xblk = 0; c.fblk = 0; c.spre = 0; c.scur = 0;
+                    c.br_phase = 2;
+                }
+            } else {
+                c.fcur = val;
+                c.br_iter++;
+                if (c.br_iter >= 100) { done = true; root = c.xcur; }
+            }
+            if (!done) {
+                if (brent_advance(c)) { done = true; root = c.xcur; }
+                else {
+                    c.dense_x = (c.xcur - c.sol_t_old) / c.sol_h;
+                    c.action = A_DENSE;
+                    break;
+                }
+            }
+            t_events[(int64_t)c.br_e * c.max_events + c.n_events[c.br_e]] = root;
+            c.n_events[c.br_e]++;
+            c.ev_pending &= ~(1 << c.br_e);
+            pc = PC_EVENTS;
             continue;
         }
         break;
@@ -202,7 +285,8 @@ __device__ __forceinline__ void radau_control_step(RadauCtl& c, const double (&g
 }
 
 __global__ void __launch_bounds__(64) radau_control_kernel(RadauCtl* __restrict__ ctls, const double* __restrict__ rec, int64_t B, int64_t n,
-                                                           int32_t* __restrict__ counts, int32_t* __restrict__ lists)
+                                                           int32_t* __restrict__ counts, int32_t* __restrict__ lists,
+                                                           const double* __restrict__ rec_dense = nullptr, double* __restrict__ t_events = nullptr)
 {
     const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
@@ -210,7 +294,13 @@ __global__ void __launch_bounds__(64) radau_control_kernel(RadauCtl* __restrict_
     if (c.pc == PC_DONE) return;
     const double* r = rec + b * 8;
     const double g_now[7] = {r[1], r[2], r[3], r[5] - 1.0, r[6] - 1.0, r[4], r[7]};   // record_to_events (marl_api.hip)
-    radau_control_step(c, g_now, n);
+    double g_dense[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (rec_dense) {
+        const double* d = rec_dense + b * 8;
+        const double gd[7] = {d[1], d[2], d[3], d[5] - 1.0, d[6] - 1.0, d[4], d[7]};
+        for (int e = 0; e < 7; e++) g_dense[e] = gd[e];
+    }
+    radau_control_step(c, g_now, n, g_dense, t_events ? t_events + b * 7 * c.max_events : nullptr);
     const int pc = c.pc;
     ctls[b] = c;
     if (pc != PC_DONE) atomicAdd(&counts[L_RUNNING], 1);
@@ -221,6 +311,21 @@ __global__ void __launch_bounds__(64) radau_control_kernel(RadauCtl* __restrict_
     if (c.action & A_LU) push(L_LU);
     if (c.action & A_NEWTON) push(L_NEWTON);
     if (c.action & (A_ERR | A_ERR2)) push(L_ERR);
+    if (c.action & A_DENSE) push(L_DENSE);
+}
+
+// A_DENSE: the dense output of the step just accepted at x = ctl.dense_x (RadauDenseOutput, radau.py:557-572; dense_eval_kernel) -> out
+__global__ void __launch_bounds__(256) dense_eval_batch_kernel(const double* __restrict__ Q, const double* __restrict__ yold, int64_t n, double* __restrict__ out,
+                                                               ZBatch B)
+{
+    if (z_masked_out(B)) return;
+    const RadauCtl* c = ctl_of(B);
+    Q = z_shift(Q, B); yold = z_shift(yold, B); out = z_shift(out, B);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double q0 = Q[3 * i], q1 = Q[3 * i + 1], q2 = Q[3 * i + 2], yo = yold[i];
+    const double p1 = c->dense_x, p2 = p1 * p1, p3 = p2 * p1;
+    out[i] = ((q0 * p1 + q1 * p2) + q2 * p3) + yo;
 }
 
 // ---- element-wise kernels of the batch (blockIdx.z = instance; scalars from the instance's controller) ---------------------

@@ -216,6 +216,48 @@ def test_radau_sweep_equals_instance_by_instance(torch_cuda_radau, oracle):
     np.testing.assert_allclose(got[0].reshape(5, N), gold, rtol=0.1, atol=0.01)
 
 
+def test_radau_sweep_locates_event_roots_like_the_single_run(torch_cuda_radau):
+    """VERDICT r2 missing #3: the reference prints and stores t_events for EVERY run (Evolve_scenario.py:118-145, 175-177); a sweep now
+    locates the monitors' roots itself (marl_sweep_radau_events_dev: Brent on the accepted step's dense output as a device-side state
+    machine).  Scenario A and the Matlab case inside a sweep: the same statistics as without root finding (locating roots must not
+    disturb the integration), the same number of roots as sign changes, and root times equal to the single run's (which are pinned
+    to scipy's by test_radau_reproduces_scipy_on_the_reference_rhs)."""
+    torch = torch_cuda_radau
+    from dataclasses import asdict
+    from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
+    from marlpde_amd.parameters import Map_Scenario
+    N = 200
+    base = asdict(Map_Scenario()) | {"N": N}
+    inst = [{"Phi0": 0.6, "PhiIni": 0.5, "PhiNR": 0.6}, {"Phi0": 0.5, "PhiIni": 0.5, "PhiNR": 0.5, "k3": 0.01, "k4": 0.01},
+            {"Phi0": 0.6, "PhiIni": 0.6, "PhiNR": 0.6}, {}]      # ... and the high-porosity default scenario (porosity crosses one twice, W changes sign hundreds of times)
+    y0 = np.stack([np.concatenate([np.full(N, (base | d)[k]) for k in ("CAIni", "CCIni", "cCaIni", "cCO3Ini", "PhiIni")]) for d in inst])
+    eq = LMAHeureuxPorosityDiff.from_scenario(base, device=0, instances=inst)
+    eq.use_stream(torch.cuda.current_stream().cuda_stream)
+    out = {}
+    for ev in (False, True):
+        yd = torch.from_numpy(y0).cuda()
+        res = eq.sweep_radau_device(yd.data_ptr(), (0.0, 1.0), 1e-6, 1e-3, 1e-3, events=ev, max_events=2048)
+        out[ev] = (yd.cpu().numpy(), res)
+    eq.close()
+    assert np.array_equal(out[False][0], out[True][0])
+    for a, b in zip(out[False][1], out[True][1]):
+        assert (a.status, a.nfev, a.njev, a.nlu, a.n_accepted, a.n_rejected) == (b.status, b.nfev, b.njev, b.nlu, b.n_accepted, b.n_rejected)
+        assert list(a.n_events) == list(b.n_events) == [len(t) for t in b.t_events]
+        assert all(np.all(np.isfinite(t)) and np.all(np.diff(t) >= 0) and np.all((t >= 0) & (t <= 1)) for t in b.t_events)
+    print("roots per instance", [[len(t) for t in r.t_events] for r in out[True][1]])
+    for b in (0, 1):
+        one = LMAHeureuxPorosityDiff.from_scenario(base | inst[b], device=0)
+        ref = one.integrate_radau(y0[b], (0.0, 1.0), 1e-6, 1e-3, 1e-3)
+        one.close()
+        got = out[True][1][b]
+        assert (got.nfev, got.njev, got.nlu, got.n_accepted) == (ref.nfev, ref.njev, ref.nlu, ref.n_accepted)
+        assert [len(t) for t in got.t_events] == [len(t) for t in ref.t_events] and sum(len(t) for t in ref.t_events) > 0
+        for e in range(7):
+            # (min(CA) grazes zero with slope ~2e-4 in Scenario A: the root is ill-conditioned - test_oracle_radau.py; the two controllers'
+            #  step sizes differ in the last bits: sqrt / pow of two libms)
+            assert np.allclose(got.t_events[e], ref.t_events[e], rtol=0, atol=5e-4), (b, e, got.t_events[e], ref.t_events[e])
+
+
 def test_radau_sweep_wg_agrees_with_the_launch_path(torch_cuda_radau):
     """Option radau_sweep_wg = 1: ONE persistent workgroup integrates an instance from start to end (marl_radau_wg.h; opt-in - measured
     slower than the launch-per-action cycle so far).  Same step-logic function, restated kernel bodies: the two paths must
