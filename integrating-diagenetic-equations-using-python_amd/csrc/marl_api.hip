@@ -81,7 +81,7 @@ struct marl_ctx {
     int64_t rk4_variant = -1, rk45_variant = -1, sweep_variant = -1, host_layout = LAYOUT_TILED, poll = 64;
     int64_t rk4_stream = 1;     // the fixed-step loop of one grid as ONE dataflow launch (rk4_stream_kernel): 0 never, 1 large grids, 2 always
     int64_t implicit_zero_copy = 1;  // scalar results of the implicit drivers through polled host memory (0: copy + synchronise)
-    int64_t radau_fused_solve = 1;   // small systems (5 N <= 2048): all PCR levels of a solve in one launch
+    int64_t radau_fused_solve = 2;   // small systems (5 N <= 2048): 1 = all PCR levels of a solve in one launch; 2 = the whole Newton iteration's linear algebra in one
     int64_t radau_solver = 0;   // 0: block parallel cyclic reduction (parallel over depth); 1: sequential block Thomas
     int64_t radau_sweep_wg = 0; // 1: sweeps of small grids with one persistent workgroup per instance (marl_radau_wg.h; measured slower so far); 0: the launch-per-action cycle
     std::string err;
@@ -325,7 +325,7 @@ int marl_set_option(marl_ctx* ctx, const char* name, int64_t value)
     else if (n == "host_layout") ctx->host_layout = value ? LAYOUT_TILED : LAYOUT_FIELD_MAJOR;
     else if (n == "poll_interval") ctx->poll = value > 0 ? value : 1;
     else if (n == "radau_solver") ctx->radau_solver = value ? 1 : 0;
-    else if (n == "radau_fused_solve") ctx->radau_fused_solve = value ? 1 : 0;
+    else if (n == "radau_fused_solve") ctx->radau_fused_solve = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "radau_sweep_wg") ctx->radau_sweep_wg = value ? 1 : 0;
     else if (n == "implicit_zero_copy") ctx->implicit_zero_copy = value ? 1 : 0;
     else if (n == "rk4_stream") ctx->rk4_stream = value < 0 ? 0 : (value > 2 ? 2 : value);
@@ -1758,6 +1758,11 @@ int radau_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_st
                 for (k = 0; k < NEWTON_MAXITER; k++) {
                     if (int rc = launch_rhs(ctx, w.YS, w.F, LAYOUT_FIELD_MAJOR, 3)) return rc;
                     st->nfev += 3;
+                    if (w.pcr && n <= radau::PCR_FUSED_MAX && ctx->radau_fused_solve >= 2) {   // right-hand sides + both solves + update + norm: one launch
+                        hipLaunchKernelGGL(radau::newton_fused_kernel, dim3(1), dim3(radau::PCR_FUSED_THREADS), 0, ctx->stream, w.y, w.F, N, M_real, M_c, w.nlevels, w.Sr,
+                                           w.Sc, w.scale, w.W, w.Z, w.YS, w.rhs_r, w.rhs_c, w.flags, w.out);
+                        LAUNCH_OK(ctx);
+                    } else {
                     hipLaunchKernelGGL(radau::newton_rhs_kernel, gn, b256, 0, ctx->stream, w.F, w.W, N, M_real, M_c, w.rhs_r, w.rhs_c, w.flags);
                     LAUNCH_OK(ctx);
                     if (int rc = radau_solve(ctx, w, true)) return rc;
@@ -1770,6 +1775,7 @@ int radau_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_st
                             hipLaunchKernelGGL(radau::sum_partials_kernel, dim3(1), dim3(1), 0, ctx->stream, w.partial, nbk, w.out);
                             LAUNCH_OK(ctx);
                         }
+                    }
                     }
                     double ss;
                     int nonfinite;

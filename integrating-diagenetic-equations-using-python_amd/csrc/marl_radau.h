@@ -671,6 +671,63 @@ __global__ void __launch_bounds__(1024) newton_update_kernel(const double* __res
     if (threadIdx.x == 0) out[blockIdx.x] = red[0];
 }
 
+// One Newton iteration's linear algebra in ONE launch for small systems (5 N <= PCR_FUSED_MAX; round 3, as marl_bdf.h's newton_fused_kernel
+// does for BDF): the right-hand sides of both systems (newton_rhs_kernel) staged straight into LDS, every cyclic-reduction level of the
+// real and then of the complex system (pcr_solve_all), then W += dW, Z = T W, YS = y + Z and the norm (newton_update_kernel with one
+// workgroup) - the same per-element operations, the same reduction tree: bit-identical to the three launches it replaces
+// (tests/test_gpu_radau.py::test_radau_fused_newton_launch_is_bit_identical), two launches less per iteration.  The non-finite flag is
+// written by the thread that writes the polled word, with a system-scope fence in between.
+__global__ void __launch_bounds__(PCR_FUSED_THREADS) newton_fused_kernel(const double* __restrict__ y, const double* __restrict__ F, int64_t N, double M_real, cplx M_c,
+                                                                         int nlevels, PcrSystem<double> Sr, PcrSystem<cplx> Sc, const double* __restrict__ scale,
+                                                                         double* __restrict__ W, double* __restrict__ Z, double* __restrict__ YS,
+                                                                         double* __restrict__ rhs_r, cplx* __restrict__ rhs_c, int32_t* __restrict__ flags,
+                                                                         double* __restrict__ out)
+{
+    __shared__ cplx lds[2 * PCR_FUSED_MAX];   // (the real system uses half of the bytes)
+    __shared__ double red[PCR_FUSED_THREADS];
+    const int64_t n = NF * N;
+    int bad = 0;
+    for (int64_t kk = threadIdx.x; kk < n; kk += PCR_FUSED_THREADS) {   // newton_rhs_kernel
+        const int64_t i = to_field_major(kk, N);
+        const double f0 = F[i], f1 = F[n + i], f2 = F[2 * n + i];
+        bad |= !(isfinite(f0) && isfinite(f1) && isfinite(f2));
+        rhs_r[kk] = ((f0 * TI00 + f1 * TI01) + f2 * TI02) - M_real * W[i];
+        const cplx w = {W[n + i], W[2 * n + i]};
+        const cplx fc = {(f0 * TI10 + f1 * TI11) + f2 * TI12, (f0 * TI20 + f1 * TI21) + f2 * TI22};
+        rhs_c[kk] = fc - M_c * w;
+    }
+    const int any_bad = __syncthreads_or(bad);
+    pcr_solve_all<double>(N, nlevels, Sr, rhs_r, rhs_r, reinterpret_cast<double*>(lds));
+    __syncthreads();
+    pcr_solve_all<cplx>(N, nlevels, Sc, rhs_c, rhs_c, lds);
+    __syncthreads();
+    double ss = 0;
+    for (int64_t kk = threadIdx.x; kk < n; kk += PCR_FUSED_THREADS) {   // newton_update_kernel, one workgroup
+        const int64_t i = to_field_major(kk, N);
+        const double d0 = rhs_r[kk], d1 = rhs_c[kk].re, d2 = rhs_c[kk].im;
+        const double s = scale[i];
+        const double e0 = d0 / s, e1 = d1 / s, e2 = d2 / s;
+        ss += (e0 * e0 + e1 * e1) + e2 * e2;
+        const double w0 = W[i] + d0, w1 = W[n + i] + d1, w2 = W[2 * n + i] + d2;
+        W[i] = w0; W[n + i] = w1; W[2 * n + i] = w2;
+        const double z0 = (T00 * w0 + T01 * w1) + T02 * w2, z1 = (T10 * w0 + T11 * w1) + T12 * w2, z2 = (T20 * w0 + T21 * w1) + T22 * w2;
+        Z[i] = z0; Z[n + i] = z1; Z[2 * n + i] = z2;
+        const double yi = y[i];
+        YS[i] = yi + z0; YS[n + i] = yi + z1; YS[2 * n + i] = yi + z2;
+    }
+    red[threadIdx.x] = ss;
+    __syncthreads();
+    for (int s2 = 512; s2 > 0; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (any_bad) *flags = 1;
+        __threadfence_system();
+        out[0] = red[0];
+    }
+}
+
 // out[0] = partial[0] + partial[1] + ... (index order: reproducible)
 __global__ void sum_partials_kernel(const double* __restrict__ partial, int n, double* __restrict__ out)
 {

@@ -216,6 +216,24 @@ def test_radau_sweep_equals_instance_by_instance(torch_cuda_radau, oracle):
     np.testing.assert_allclose(got[0].reshape(5, N), gold, rtol=0.1, atol=0.01)
 
 
+@pytest.mark.parametrize("name", ["A", "matlab", "A_N64_tight"])
+def test_radau_fused_newton_launch_is_bit_identical(name):
+    """Small systems (5 N <= 2048): the right-hand sides of both collocation systems, every cyclic-reduction level of both solves, the
+    update and the norm of a Newton iteration in ONE launch (radau::newton_fused_kernel, option radau_fused_solve = 2, the default)
+    against the one-launch solves (1) and the per-level launches (0): the same arithmetic in the same order."""
+    g, p, eq = _model(name)
+    out = []
+    for fused in (0, 1, 2):
+        eq.set_option("radau_fused_solve", fused)
+        out.append(eq.integrate_radau(g["y0"], tuple(g["t_span"]), float(g["first_step"]), float(g["rtol"]), float(g["atol"])))
+    eq.close()
+    for b in out[1:]:
+        a = out[0]
+        assert (a.status, a.nfev, a.njev, a.nlu, a.n_accepted, a.n_rejected) == (b.status, b.nfev, b.njev, b.nlu, b.n_accepted, b.n_rejected)
+        assert np.array_equal(a.y_final, b.y_final)
+        assert all(np.array_equal(x, y) for x, y in zip(a.t_events, b.t_events))
+
+
 def test_radau_sweep_locates_event_roots_like_the_single_run(torch_cuda_radau):
     """VERDICT r2 missing #3: the reference prints and stores t_events for EVERY run (Evolve_scenario.py:118-145, 175-177); a sweep now
     locates the monitors' roots itself (marl_sweep_radau_events_dev: Brent on the accepted step's dense output as a device-side state
@@ -251,7 +269,9 @@ def test_radau_sweep_locates_event_roots_like_the_single_run(torch_cuda_radau):
         one.close()
         got = out[True][1][b]
         assert (got.nfev, got.njev, got.nlu, got.n_accepted) == (ref.nfev, ref.njev, ref.nlu, ref.n_accepted)
-        assert [len(t) for t in got.t_events] == [len(t) for t in ref.t_events] and sum(len(t) for t in ref.t_events) > 0
+        assert [len(t) for t in got.t_events] == [len(t) for t in ref.t_events]
+        if b == 0:
+            assert [len(t) for t in ref.t_events][:2] == [1, 1]      # Scenario A: the aragonite fraction reaches zero (min(y) and min(CA) cross together)
         for e in range(7):
             # (min(CA) grazes zero with slope ~2e-4 in Scenario A: the root is ill-conditioned - test_oracle_radau.py; the two controllers'
             #  step sizes differ in the last bits: sqrt / pow of two libms)
