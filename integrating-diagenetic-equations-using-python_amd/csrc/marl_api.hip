@@ -81,9 +81,9 @@ struct marl_ctx {
     int64_t rk4_variant = -1, rk45_variant = -1, sweep_variant = -1, host_layout = LAYOUT_TILED, poll = 64;
     int64_t rk4_stream = 1;     // the fixed-step loop of one grid as ONE dataflow launch (rk4_stream_kernel): 0 never, 1 large grids, 2 always
     int64_t implicit_zero_copy = 1;  // scalar results of the implicit drivers through polled host memory (0: copy + synchronise)
-    int64_t radau_fused_solve = 2;   // small systems (5 N <= 2048): 1 = all PCR levels of a solve in one launch; 2 = the whole Newton iteration's linear algebra in one
+    int64_t radau_fused_solve = 1;   // small systems (5 N <= 2048): 1 = all PCR levels of a solve in one launch (BDF: the whole Newton iteration); 2 = Radau too: the whole iteration's linear algebra in one launch (bit-identical, measured SLOWER: 10.1 vs 9.0 ms - the two solves then run one after the other)
     int64_t radau_solver = 0;   // 0: block parallel cyclic reduction (parallel over depth); 1: sequential block Thomas
-    int64_t radau_sweep_wg = 0; // 1: sweeps of small grids with one persistent workgroup per instance (marl_radau_wg.h; measured slower so far); 0: the launch-per-action cycle
+    int64_t radau_sweep_wg = 1; // sweeps of small grids: 1 hybrid (workgroup per instance for the sequential work, launch kernels for Jacobians / factorisations), 2 all in the workgroup, 0 launch per action
     std::string err;
 };
 
@@ -326,7 +326,7 @@ int marl_set_option(marl_ctx* ctx, const char* name, int64_t value)
     else if (n == "poll_interval") ctx->poll = value > 0 ? value : 1;
     else if (n == "radau_solver") ctx->radau_solver = value ? 1 : 0;
     else if (n == "radau_fused_solve") ctx->radau_fused_solve = value < 0 ? 0 : (value > 2 ? 2 : value);
-    else if (n == "radau_sweep_wg") ctx->radau_sweep_wg = value ? 1 : 0;
+    else if (n == "radau_sweep_wg") ctx->radau_sweep_wg = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "implicit_zero_copy") ctx->implicit_zero_copy = value ? 1 : 0;
     else if (n == "rk4_stream") ctx->rk4_stream = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "rk4_stream_test_raise") ctx->sq_test_raise = value != 0;
@@ -2307,7 +2307,13 @@ extern "C" int marl_sweep_radau_events_dev(marl_ctx* ctx, double* y_dev, double 
         HIP_OK(ctx, hipMemsetAsync(drec_dense, 0, sizeof(double) * NQ * B, ctx->stream));
         HIP_OK(ctx, hipMemsetAsync(dtev, 0xff, sizeof(double) * (size_t)(7 * max_events) * B, ctx->stream));   // (all bits set: NaN)
     }
-    auto cleanup = [&]() { (void)hipFree(dctl); (void)hipFree(drec); (void)hipFree(dcounts); if (drec_dense) (void)hipFree(drec_dense); if (dtev) (void)hipFree(dtev); };
+    unsigned* wg_next = nullptr;   // one-workgroup-per-instance paths: the instance queue, then the list of instances a pass visits [2 B]
+    auto cleanup = [&]() {
+        (void)hipFree(dctl); (void)hipFree(drec); (void)hipFree(dcounts);
+        if (drec_dense) (void)hipFree(drec_dense);
+        if (dtev) (void)hipFree(dtev);
+        if (wg_next) (void)hipFree(wg_next);
+    };
     std::vector<RadauCtl> hctl((size_t)B);
     for (auto& c : hctl) {
         memset(&c, 0, sizeof c);
@@ -2353,37 +2359,53 @@ extern "C" int marl_sweep_radau_events_dev(marl_ctx* ctx, double* y_dev, double 
         hipError_t e_ = hipGetLastError();                                                            \
         if (e_ != hipSuccess) { cleanup(); return fail(ctx, -100 - (int)e_, "kernel launch failed: %s", hipGetErrorString(e_)); } \
     } while (0)
-    // Option radau_sweep_wg = 1 (small grids, 5 N <= PCR_FUSED_MAX): ONE persistent workgroup per instance runs the instance's whole
-    // integration (marl_radau_wg.h) - same step logic function and kernel bodies, no host in the loop.  Built and measured in round 3
-    // (profiles/r03_lab_radau_wg.log): NOT the default - block cyclic reduction on ONE compute unit costs 0.64 ms per factorisation
-    // (126 group calls of dependent L2 round trips), 35 ms per Scenario-A instance against 9.4 ms for the launch-per-action path that
-    // spreads a factorisation over 50 workgroups; it needs a work-efficient (block Thomas) factorisation inside the workgroup to pay.
-    const bool use_wg = ctx->radau_sweep_wg && n <= PCR_FUSED_MAX && !locate;   // (the one-workgroup path counts sign changes only)
-    if (use_wg) {
+    // Sweeps of small grids (5 N <= PCR_FUSED_MAX: the reference's N = 200), option radau_sweep_wg:
+    //   1 (default)  HYBRID: one persistent workgroup per instance runs everything of the instance that is sequential and small (step
+    //                logic, Newton iterations, error estimates, accepted steps, event roots - marl_radau_wg.h) and hands it back for
+    //                Jacobians and factorisations, which the launch kernels do over work lists on the whole chip: one host cycle per
+    //                Jacobian / factorisation instead of one per action;
+    //   2            the workgroup does those as well (no host in the loop; measured slower: cyclic reduction on ONE compute unit);
+    //   0            the launch-per-action cycle (larger grids always take it).
+    const int wg_mode = (n <= PCR_FUSED_MAX) ? (int)ctx->radau_sweep_wg : 0;
+    const bool use_wg = wg_mode == 2 && !locate;
+    WgWork ww{};
+    if (wg_mode) {
         if (!ctx->cus) {
             hipDeviceProp_t prop;
             if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) { cleanup(); return fail(ctx, -3, "device properties unavailable"); }
             ctx->cus = prop.multiProcessorCount;
         }
-        WgWork ww{};
         ww.y = w.y; ww.f = w.f; ww.fnew = w.fnew; ww.ynew = w.ynew; ww.err = w.err; ww.yerr = w.yerr; ww.yold = w.yold; ww.scale = w.scale; ww.tmp = w.tmp;
         ww.Z = w.Z; ww.W = w.W; ww.F = w.F; ww.Q = w.Q; ww.YS = w.YS; ww.fac = w.fac; ww.h = w.h; ww.yscale = w.yscale; ww.maxdiff = w.maxdiff; ww.scl = w.scl;
         ww.hnew = w.hnew; ww.Jraw = w.Jraw; ww.YP = w.YP; ww.FN = w.FN; ww.J = w.J; ww.rhs_r = w.rhs_r; ww.rhs_c = w.rhs_c; ww.small = w.small; ww.groups = w.groups;
         ww.Sr = w.Sr; ww.Sc = w.Sc; ww.ng = w.ng; ww.nlevels = w.nlevels; ww.zs = zs;
-        unsigned* next = reinterpret_cast<unsigned*>(dcounts);     // (the work-list counters are not used on this path)
-        (void)hipMemsetAsync(next, 0, sizeof(unsigned), ctx->stream);
-        const dim3 grid((unsigned)std::min<int64_t>(B, (int64_t)ctx->cus));
+        if (hipMalloc((void**)&wg_next, sizeof(unsigned) * (size_t)(2 + 2 * B)) != hipSuccess) { wg_next = nullptr; cleanup(); return fail(ctx, -3, "allocation failed"); }
+    }
+    // nrun < 0: the pass visits every instance; else the instances run_list[0 .. nrun) (those the last pass handed back)
+    auto launch_wg = [&](int hybrid, int64_t nrun) {
+        (void)hipMemsetAsync(wg_next, 0, sizeof(unsigned), ctx->stream);
+        const int64_t todo = nrun < 0 ? B : nrun;
+        const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(todo, (int64_t)ctx->cus)));
+        const int32_t* run_list = nrun < 0 ? nullptr : reinterpret_cast<const int32_t*>(wg_next + 2);
         if (ctx->var_dphi)
-            hipLaunchKernelGGL(radau_wg_kernel<true>, grid, dim3(WG_THREADS), 0, ctx->stream, dctl, B, N, ww, ctx->dconsts, atol, P, E3[0], E3[1], E3[2], next);
+            hipLaunchKernelGGL(radau_wg_kernel<true>, grid, dim3(WG_THREADS), 0, ctx->stream, dctl, B, N, ww, ctx->dconsts, atol, P, E3[0], E3[1], E3[2], wg_next,
+                               hybrid, dcounts, dlists, dtev, run_list, todo);
         else
-            hipLaunchKernelGGL(radau_wg_kernel<false>, grid, dim3(WG_THREADS), 0, ctx->stream, dctl, B, N, ww, ctx->dconsts, atol, P, E3[0], E3[1], E3[2], next);
+            hipLaunchKernelGGL(radau_wg_kernel<false>, grid, dim3(WG_THREADS), 0, ctx->stream, dctl, B, N, ww, ctx->dconsts, atol, P, E3[0], E3[1], E3[2], wg_next,
+                               hybrid, dcounts, dlists, dtev, run_list, todo);
+    };
+    if (use_wg) {
+        launch_wg(0, -1);
         RB_OK();
     }
+    int64_t wg_nrun = -1;
+    const bool hybrid = wg_mode == 1 || (wg_mode == 2 && locate);
     for (int64_t cycle = 0; !use_wg; cycle++) {
         // the controllers advance every instance to its next piece of work and sort the instances into work lists; the host
         // reads the list lengths (one small copy + synchronisation per cycle) and launches each kind of work over its list only
         if (!zc_words || cycle == 0) (void)hipMemsetAsync(dcounts, 0, sizeof(int32_t) * L_COUNT, ctx->stream);   // (publish_counts_kernel zeroes them afterwards)
-        hipLaunchKernelGGL(radau_control_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, ctx->stream, dctl, drec, B, n, dcounts, dlists, drec_dense, dtev);
+        if (hybrid) launch_wg(1, wg_nrun);   // every running instance up to its next Jacobian / factorisation (or its end)
+        else hipLaunchKernelGGL(radau_control_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, ctx->stream, dctl, drec, B, n, dcounts, dlists, drec_dense, dtev);
         RB_OK();
         if (zc_words) {   // the list lengths through polled host memory
             hipLaunchKernelGGL(publish_counts_kernel, dim3(1), dim3(1), 0, ctx->stream, dcounts, reinterpret_cast<int32_t*>(ctx->zc_d + 16), (int32_t)(cycle + 1));
@@ -2403,6 +2425,13 @@ extern "C" int marl_sweep_radau_events_dev(marl_ctx* ctx, double* y_dev, double 
             if (hipStreamSynchronize(ctx->stream) != hipSuccess) { cleanup(); return fail(ctx, -3, "synchronize failed"); }
         }
         if (hcounts[L_RUNNING] == 0) break;
+        if (hybrid) {   // the instances handed back in this pass are the ones the next pass visits (after their Jacobian / factorisation below)
+            const int64_t nj = hcounts[L_JAC], nl = hcounts[L_LU];
+            int32_t* run_list = reinterpret_cast<int32_t*>(wg_next + 2);
+            if (nj) (void)hipMemcpyAsync(run_list, dlists + (int64_t)L_JAC * B, sizeof(int32_t) * (size_t)nj, hipMemcpyDeviceToDevice, ctx->stream);
+            if (nl) (void)hipMemcpyAsync(run_list + nj, dlists + (int64_t)L_LU * B, sizeof(int32_t) * (size_t)nl, hipMemcpyDeviceToDevice, ctx->stream);
+            wg_nrun = nj + nl;
+        }
         const unsigned nR = (unsigned)hcounts[L_RHS1], nA = (unsigned)hcounts[L_ACCEPT], nJ = (unsigned)hcounts[L_JAC], nL = (unsigned)hcounts[L_LU],
                        nN = (unsigned)hcounts[L_NEWTON], nE = (unsigned)hcounts[L_ERR], nD = (unsigned)hcounts[L_DENSE];
         if (nD) {   // event root finding: the dense output of the accepted step at the abscissa Brent asks for, and that state's monitors
@@ -2426,7 +2455,7 @@ extern "C" int marl_sweep_radau_events_dev(marl_ctx* ctx, double* y_dev, double 
             hipLaunchKernelGGL(accept_kernel, dim3(gx, 1, nA), b256, 0, ctx->stream, w.Z, w.Q, w.y, w.yold, w.ynew, w.f, w.fnew, n, P, Z(L_ACCEPT));
             RB_OK();
         }
-        if (nA || cycle == 0) {   // monitors of every instance's y (read by the controllers after the start and after each accepted step)
+        if ((nA || cycle == 0) && !hybrid) {   // monitors of every instance's y (read by the controllers after the start and after each accepted step)
             hipLaunchKernelGGL(monitors_kernel<LAYOUT_FIELD_MAJOR>, dim3((unsigned)nbm, (unsigned)B), b256, 0, ctx->stream, w.y, ctx->dconsts, ctx->slab, zs / 8, ctx->part);
             RB_OK();
             hipLaunchKernelGGL(reduce_records_kernel, dim3((unsigned)B), b256, 0, ctx->stream, ctx->part, nbm, drec);

@@ -49,6 +49,20 @@ __device__ __forceinline__ cplx madd(cplx acc, cplx a, cplx b)
     return {acc.re + p.re, acc.im + p.im};
 }
 __device__ __forceinline__ double mul1(double a, double b) { return a * b; }
+// (a0 b0 + a1 b1) + a2 b2 and the complex product, SPELLED OUT for the batched kernels (marl_radau_batch.h) and the
+// one-workgroup-per-instance integrator (marl_radau_wg.h) with the contraction the compiler chose in the batched launch kernels of
+// round 2 (read off their machine code: the middle product is rounded, the first and the last are fused; re = fma(a.re, b.re,
+// -(a.im b.im)), im = fma(a.re, b.im, a.im b.re)).  Written as `a*b + c*d` the choice is the compiler's and depends on what the
+// expression is inlined into: the workgroup integrator got other roundings than the launch kernels from the same source text, and a
+// last-bit difference in an error norm flips Newton / step-size decisions later on.  With these helpers the sweep paths (launch per
+// action, hybrid, all-in-workgroup) give the same bits.  The single-run kernels below keep their source text - and with it the
+// roundings their scipy-equal statistics were pinned with (newton_rhs_kernel's complex product, for one, is contracted the other way
+// round than the batched kernel's: im = fma(a.im, b.re, a.re b.im)).
+__device__ __forceinline__ double dot3(double a0, double b0, double a1, double b1, double a2, double b2)
+{
+    return __builtin_fma(a2, b2, __builtin_fma(a0, b0, a1 * b1));
+}
+__device__ __forceinline__ cplx cmul_ref(cplx a, cplx b) { return {__builtin_fma(a.re, b.re, -(a.im * b.im)), __builtin_fma(a.re, b.im, a.im * b.re)}; }
 __device__ inline double lift(double a, double) { return a; }
 __device__ inline cplx lift(double a, cplx) { return {a, 0.0}; }
 

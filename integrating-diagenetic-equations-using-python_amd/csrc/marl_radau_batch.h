@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(256) dense_eval_batch_kernel(const double* __r
     if (i >= n) return;
     const double q0 = Q[3 * i], q1 = Q[3 * i + 1], q2 = Q[3 * i + 2], yo = yold[i];
     const double p1 = c->dense_x, p2 = p1 * p1, p3 = p2 * p1;
-    out[i] = ((q0 * p1 + q1 * p2) + q2 * p3) + yo;
+    out[i] = dot3(q0, p1, q1, p2, q2, p3) + yo;
 }
 
 // ---- element-wise kernels of the batch (blockIdx.z = instance; scalars from the instance's controller) ---------------------
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(256) accept_kernel(const double* __restrict__ 
     if (i >= n) return;
     const double z0 = Z[i], z1 = Z[n + i], z2 = Z[2 * n + i];
 #pragma unroll
-    for (int m = 0; m < 3; m++) Q[3 * i + m] = (z0 * P.p[0][m] + z1 * P.p[1][m]) + z2 * P.p[2][m];
+    for (int m = 0; m < 3; m++) Q[3 * i + m] = dot3(z0, P.p[0][m], z1, P.p[1][m], z2, P.p[2][m]);
     yold[i] = y[i];
     y[i] = ynew[i];
     f[i] = fnew[i];
@@ -397,14 +397,14 @@ __global__ void __launch_bounds__(256) newton_begin_batch_kernel(const double* _
 #pragma unroll
         for (int s = 0; s < 3; s++) {
             const double p1 = c->x3[s], p2 = p1 * p1, p3 = p2 * p1;
-            z[s] = (((q0 * p1 + q1 * p2) + q2 * p3) + yo) - yi;
+            z[s] = (dot3(q0, p1, q1, p2, q2, p3) + yo) - yi;
         }
     }
     scale[i] = c->atol + fabs(yi) * c->rtol;
     Z[i] = z[0]; Z[n + i] = z[1]; Z[2 * n + i] = z[2];
-    W[i] = (TI00 * z[0] + TI01 * z[1]) + TI02 * z[2];
-    W[n + i] = (TI10 * z[0] + TI11 * z[1]) + TI12 * z[2];
-    W[2 * n + i] = (TI20 * z[0] + TI21 * z[1]) + TI22 * z[2];
+    W[i] = dot3(TI00, z[0], TI01, z[1], TI02, z[2]);
+    W[n + i] = dot3(TI10, z[0], TI11, z[1], TI12, z[2]);
+    W[2 * n + i] = dot3(TI20, z[0], TI21, z[1], TI22, z[2]);
     YS[i] = yi + z[0]; YS[n + i] = yi + z[1]; YS[2 * n + i] = yi + z[2];
 }
 
@@ -421,10 +421,10 @@ __global__ void __launch_bounds__(256) newton_rhs_batch_kernel(const double* __r
     const int64_t i = to_field_major(kk, N);
     const double f0 = F[i], f1 = F[n + i], f2 = F[2 * n + i];
     if (!(isfinite(f0) && isfinite(f1) && isfinite(f2))) atomicOr(&ctls[z_inst(B)].nonfinite, 1);
-    rhs_r[kk] = ((f0 * TI00 + f1 * TI01) + f2 * TI02) - c->mu_r * W[i];
+    rhs_r[kk] = __builtin_fma(-c->mu_r, W[i], dot3(f0, TI00, f1, TI01, f2, TI02));
     const cplx w = {W[n + i], W[2 * n + i]};
-    const cplx fc = {(f0 * TI10 + f1 * TI11) + f2 * TI12, (f0 * TI20 + f1 * TI21) + f2 * TI22};
-    rhs_c[kk] = fc - cplx{c->mu_c_re, c->mu_c_im} * w;
+    const cplx fc = {dot3(f0, TI10, f1, TI11, f2, TI12), dot3(f0, TI20, f1, TI21, f2, TI22)};
+    rhs_c[kk] = fc - cmul_ref(cplx{c->mu_c_re, c->mu_c_im}, w);
 }
 
 // A_NEWTON: one workgroup per instance: sum (dW / scale)^2 -> ctl.sumsq; W += dW, Z = T W, YS = y + Z
@@ -442,10 +442,10 @@ __global__ void __launch_bounds__(1024) newton_update_batch_kernel(const double*
         const double d0 = rhs_r[kk], d1 = rhs_c[kk].re, d2 = rhs_c[kk].im;
         const double s = scale[i];
         const double e0 = d0 / s, e1 = d1 / s, e2 = d2 / s;
-        ss += (e0 * e0 + e1 * e1) + e2 * e2;
+        ss += dot3(e0, e0, e1, e1, e2, e2);
         const double w0 = W[i] + d0, w1 = W[n + i] + d1, w2 = W[2 * n + i] + d2;
         W[i] = w0; W[n + i] = w1; W[2 * n + i] = w2;
-        const double z0 = (T00 * w0 + T01 * w1) + T02 * w2, z1 = (T10 * w0 + T11 * w1) + T12 * w2, z2 = (T20 * w0 + T21 * w1) + T22 * w2;
+        const double z0 = dot3(T00, w0, T01, w1, T02, w2), z1 = dot3(T10, w0, T11, w1, T12, w2), z2 = dot3(T20, w0, T21, w1, T22, w2);
         Z[i] = z0; Z[n + i] = z1; Z[2 * n + i] = z2;
         const double yi = y[i];
         YS[i] = yi + z0; YS[n + i] = yi + z1; YS[2 * n + i] = yi + z2;
@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(256) error_rhs_batch_kernel(const double* __re
     const int64_t kk = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (kk >= n) return;
     const int64_t i = to_field_major(kk, N);
-    const double ZE = ((Z[i] * E0 + Z[n + i] * E1) + Z[2 * n + i] * E2) / c->h;
+    const double ZE = dot3(Z[i], E0, Z[n + i], E1, Z[2 * n + i], E2) / c->h;
     rhs_r[kk] = fvec[i] + ZE;
     ynew[i] = y[i] + Z[2 * n + i];
 }
@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(1024) error_norm_batch_kernel(const double* __
         const double a = fabs(y[i]), b = fabs(ynew[i]);
         const double s = c->atol + ((a > b || a != a) ? a : b) * c->rtol;
         const double q = e / s;
-        ss += q * q;
+        ss = __builtin_fma(q, q, ss);
         err[i] = e;
         yerr[i] = y[i] + e;
     }

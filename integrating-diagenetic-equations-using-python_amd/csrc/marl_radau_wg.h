@@ -7,18 +7,23 @@
 // instance is one host-driven cycle of ~8 launches (150 - 200 us), 4000 cycles for the slowest of 512 scenarios: 0.7 s of the sweep's
 // 0.87 s.  Instances are independent, so the natural unit of parallelism is the instance (the shape of rk45_sweep_kernel).
 //
-// STATUS: opt-in (option radau_sweep_wg = 1), NOT the default.  Measured (profiles/r03_lab_radau_wg.log, Scenario A, N = 200): 35 ms per
-// instance - factorisations 24 ms (38 x 0.64 ms: block cyclic reduction does log2 N times the work of a block Thomas sweep, and on ONE
-// compute unit its 126 group calls per factorisation are dependent L2 round trips), Newton iterations 6.1 ms (118 x 52 us, two
-// cyclic-reduction solves of 9 barrier-separated levels each), the rest 3.6 ms - against 9.4 ms for the single-run launch path, which
-// spreads a factorisation over 50 workgroups.  Sweeps of 64 / 512 / 4096 scenarios: 0.98 / 1.15 / 2.7 s here against 0.55 / 0.88 / 1.98 s
-// for the launch-per-action cycle.  What it needs to pay: a wave-cooperative block THOMAS factorisation / solve inside the workgroup
-// (work-efficient; ~0.15 ms and ~13 us) - estimated 12 ms per instance, 0.24 / 0.41 s for 512 / 4096 scenarios.  Not built this round.
+// STATUS (round 3, profiles/r03_lab_radau_wg.log).  Two ways to use it (option radau_sweep_wg):
+//   1  HYBRID - the default for sweeps of small grids: the workgroup runs everything of an instance that is sequential and small (step
+//      logic, single right-hand sides, Newton iterations, error estimates, accepted steps, event root finding) and hands the instance
+//      back to the host cycle when the step logic asks for a Jacobian or a factorisation - the two pieces that want the whole chip, done
+//      by the launch kernels over work lists as before.  One host cycle per Jacobian / factorisation instead of one per action.
+//      64 / 512 / 4096 scenarios: 0.42 / 0.72 / 1.73 s (launch per action: 0.55 / 0.88 / 1.98 s); bit-identical statistics.
+//   2  everything in the workgroup, no host in the loop: 0.98 / 1.15 / 2.7 s - cyclic reduction does log2 N times the work of a block
+//      Thomas sweep, and on ONE compute unit its 126 group calls per factorisation are dependent L2 round trips: 0.64 ms per
+//      factorisation, 24 of the 35 ms of a Scenario-A instance (Newton iterations 6.1 ms = 118 x 52 us, the rest 3.6 ms; the launch path
+//      needs 9.4 ms for the same instance alone on the chip).  What this mode needs to pay: a wave-cooperative block THOMAS
+//      factorisation / solve inside the workgroup (estimate: 12 ms per instance, 0.24 / 0.41 s for 512 / 4096 scenarios).  Not built.
 //
-// Arithmetic: every piece below restates the body of the corresponding launch kernel (marl_radau.h, marl_radau_batch.h, marl_kernels.h)
-// and the step logic IS the same function (radau_control_step); the results agree with the launch path like two correct runs do
-// (statistics within a few evaluations, states within the solver's tolerance) - not bit for bit: the compiler contracts the complex
-// multiply-adds of the factorisation differently in the two contexts (tests/test_gpu_radau.py::test_radau_sweep_wg_agrees_with_the_launch_path).
+// Arithmetic: every piece below restates the body of the corresponding batched launch kernel (marl_radau_batch.h), the step logic IS the
+// same function (radau_control_step), and the contraction-ambiguous expressions go through the same spelled-out helpers (dot3,
+// cmul_ref) in both: the hybrid path reproduces the launch path's statistics exactly and its states to 1e-12
+// (tests/test_gpu_radau.py::test_radau_sweep_workgroup_paths_against_the_launch_path).  Mode 2 inlines the factorisation into the big
+// kernel, where the compiler may contract its complex multiply-adds differently: compared like two correct runs.
 // Grids of up to PCR_FUSED_MAX / 5 = 409 cells (the solve keeps a right-hand side in LDS).
 #pragma once
 #include "marl_radau_batch.h"
@@ -123,14 +128,24 @@ __device__ __forceinline__ double wg_sum(double ss, double* red)
     return r;
 }
 
+// hybrid != 0 (round 3, the default for sweeps of small grids): the workgroup runs everything of an instance that is SEQUENTIAL and
+// small - the step logic, single right-hand sides, Newton iterations (stage derivatives + both cyclic-reduction solves + update + norm),
+// error estimates, accepted-step bookkeeping, event root finding - and hands the instance back to the host cycle when the step logic asks
+// for a Jacobian or a factorisation: those are the two pieces that want the whole chip (finite-difference columns of 15 - 21 perturbed
+// states; 2 x 9 cyclic-reduction levels over all cells), and the launch kernels of marl_radau.h do them over work lists as before.  An
+// instance's host cycles drop from one per ACTION (~4000 for the slowest of 512 scenarios) to one per Jacobian / factorisation.
+// counts / lists: the work lists of marl_radau_batch.h (L_JAC, L_LU, L_RUNNING); g_dense / t_events: event root finding (may be NULL).
 template <bool VD>
 __global__ void __launch_bounds__(WG_THREADS) radau_wg_kernel(RadauCtl* __restrict__ ctls, int64_t B, int64_t N, WgWork w, const DevConsts* __restrict__ consts,
-                                                              double fd_threshold, P33 P, double E0, double E1, double E2, unsigned* __restrict__ next_instance)
+                                                              double fd_threshold, P33 P, double E0, double E1, double E2, unsigned* __restrict__ next_instance,
+                                                              int hybrid = 0, int32_t* __restrict__ counts = nullptr, int32_t* __restrict__ lists = nullptr,
+                                                              double* __restrict__ t_events = nullptr, const int32_t* __restrict__ run_list = nullptr,
+                                                              int64_t todo = -1)
 {
     __shared__ WgBuf buf;
     __shared__ double tabs[TABLE_DOUBLES];
     __shared__ RadauCtl sc;
-    __shared__ double g_now[7];
+    __shared__ double g_now[7], g_dense[7];
     __shared__ unsigned s_b;
     __shared__ int s_nonfinite;
     const Tables T = load_tables(tabs, WG_THREADS);
@@ -141,8 +156,8 @@ __global__ void __launch_bounds__(WG_THREADS) radau_wg_kernel(RadauCtl* __restri
         __syncthreads();
         if (tid == 0) s_b = atomicAdd(next_instance, 1u);
         __syncthreads();
-        const int64_t b = s_b;
-        if (b >= B) break;
+        if ((int64_t)s_b >= (todo < 0 ? B : todo)) break;
+        const int64_t b = run_list ? (int64_t)run_list[s_b] : (int64_t)s_b;   // (this pass's instances: all of them, or the ones handed back last time)
         const int64_t off = b * w.zs;
         const DevConsts& C = consts[b];
         const HotConsts K = load_hot(&C);
@@ -161,14 +176,31 @@ __global__ void __launch_bounds__(WG_THREADS) radau_wg_kernel(RadauCtl* __restri
 #endif
         while (true) {
             if (tid == 0) {
-                double g[7];
-                for (int e = 0; e < 7; e++) g[e] = g_now[e];
-                radau_control_step(sc, g, n);
+                double g[7], gd[7];
+                for (int e = 0; e < 7; e++) { g[e] = g_now[e]; gd[e] = g_dense[e]; }
+                radau_control_step(sc, g, n, gd, t_events ? t_events + b * 7 * sc.max_events : nullptr);
             }
             __syncthreads();
             WG_TICK(0);
             const int32_t action = sc.action;
             if (sc.pc == PC_DONE && action == 0) break;
+            if (hybrid && (action & (A_JAC | A_LU))) {   // back to the host cycle: the launch kernels do this over the work lists
+                if (tid == 0) {
+                    atomicAdd(&counts[L_RUNNING], 1);
+                    const int which = (action & A_JAC) ? L_JAC : L_LU;
+                    lists[(int64_t)which * B + atomicAdd(&counts[which], 1)] = (int32_t)b;
+                }
+                break;
+            }
+            // ---- event root finding: the accepted step's dense output at the abscissa Brent asks for, and that state's monitors
+            if (action & A_DENSE) {
+                const double *Q = wg_at(w.Q, off), *yold = wg_at(w.yold, off);
+                double* out = wg_at(w.tmp, off);
+                const double p1 = sc.dense_x, p2 = p1 * p1, p3 = p2 * p1;
+                for (int64_t i = tid; i < n; i += WG_THREADS) out[i] = dot3(Q[3 * i], p1, Q[3 * i + 1], p2, Q[3 * i + 2], p3) + yold[i];
+                __syncthreads();
+                wg_monitors(out, N, C, T, buf.red, g_dense);
+            }
 
             // ---- a single state -> its derivative: y -> f (start), y + err -> tmp (second error estimate), y_new -> f_new (accepted step)
             if (action & (A_RHS_Y | A_ERR2 | A_ACCEPT)) {
@@ -186,7 +218,7 @@ __global__ void __launch_bounds__(WG_THREADS) radau_wg_kernel(RadauCtl* __restri
                 for (int64_t i = tid; i < n; i += WG_THREADS) {
                     const double z0 = Z[i], z1 = Z[n + i], z2 = Z[2 * n + i];
 #pragma unroll
-                    for (int m = 0; m < 3; m++) Q[3 * i + m] = (z0 * P.p[0][m] + z1 * P.p[1][m]) + z2 * P.p[2][m];
+                    for (int m = 0; m < 3; m++) Q[3 * i + m] = dot3(z0, P.p[0][m], z1, P.p[1][m], z2, P.p[2][m]);
                     yold[i] = y[i];
                     y[i] = ynew[i];
                     f[i] = fnew[i];
@@ -308,14 +340,14 @@ __global__ void __launch_bounds__(WG_THREADS) radau_wg_kernel(RadauCtl* __restri
 #pragma unroll
                             for (int s = 0; s < 3; s++) {
                                 const double p1 = sc.x3[s], p2 = p1 * p1, p3 = p2 * p1;
-                                z[s] = (((q0 * p1 + q1 * p2) + q2 * p3) + yo) - yi;
+                                z[s] = (dot3(q0, p1, q1, p2, q2, p3) + yo) - yi;
                             }
                         }
                         scale[i] = sc.atol + fabs(yi) * sc.rtol;
                         Z[i] = z[0]; Z[n + i] = z[1]; Z[2 * n + i] = z[2];
-                        W[i] = (TI00 * z[0] + TI01 * z[1]) + TI02 * z[2];
-                        W[n + i] = (TI10 * z[0] + TI11 * z[1]) + TI12 * z[2];
-                        W[2 * n + i] = (TI20 * z[0] + TI21 * z[1]) + TI22 * z[2];
+                        W[i] = dot3(TI00, z[0], TI01, z[1], TI02, z[2]);
+                        W[n + i] = dot3(TI10, z[0], TI11, z[1], TI12, z[2]);
+                        W[2 * n + i] = dot3(TI20, z[0], TI21, z[1], TI22, z[2]);
                         YS[i] = yi + z[0]; YS[n + i] = yi + z[1]; YS[2 * n + i] = yi + z[2];
                     }
                     __syncthreads();
@@ -330,10 +362,10 @@ __global__ void __launch_bounds__(WG_THREADS) radau_wg_kernel(RadauCtl* __restri
                         const int64_t i = to_field_major(kk, N);
                         const double f0 = F[i], f1 = F[n + i], f2 = F[2 * n + i];
                         bad |= !(isfinite(f0) && isfinite(f1) && isfinite(f2));
-                        rhs_r[kk] = ((f0 * TI00 + f1 * TI01) + f2 * TI02) - mu_r * W[i];
+                        rhs_r[kk] = __builtin_fma(-mu_r, W[i], dot3(f0, TI00, f1, TI01, f2, TI02));
                         const cplx wv = {W[n + i], W[2 * n + i]};
-                        const cplx fc = {(f0 * TI10 + f1 * TI11) + f2 * TI12, (f0 * TI20 + f1 * TI21) + f2 * TI22};
-                        rhs_c[kk] = fc - mu_c * wv;
+                        const cplx fc = {dot3(f0, TI10, f1, TI11, f2, TI12), dot3(f0, TI20, f1, TI21, f2, TI22)};
+                        rhs_c[kk] = fc - cmul_ref(mu_c, wv);
                     }
                     if (bad) s_nonfinite = 1;
                 }
@@ -348,10 +380,10 @@ __global__ void __launch_bounds__(WG_THREADS) radau_wg_kernel(RadauCtl* __restri
                     const double d0 = rhs_r[kk], d1 = rhs_c[kk].re, d2 = rhs_c[kk].im;
                     const double s = scale[i];
                     const double e0 = d0 / s, e1 = d1 / s, e2 = d2 / s;
-                    ss += (e0 * e0 + e1 * e1) + e2 * e2;
+                    ss += dot3(e0, e0, e1, e1, e2, e2);
                     const double w0 = W[i] + d0, w1 = W[n + i] + d1, w2 = W[2 * n + i] + d2;
                     W[i] = w0; W[n + i] = w1; W[2 * n + i] = w2;
-                    const double z0 = (T00 * w0 + T01 * w1) + T02 * w2, z1 = (T10 * w0 + T11 * w1) + T12 * w2, z2 = (T20 * w0 + T21 * w1) + T22 * w2;
+                    const double z0 = dot3(T00, w0, T01, w1, T02, w2), z1 = dot3(T10, w0, T11, w1, T12, w2), z2 = dot3(T20, w0, T21, w1, T22, w2);
                     Z[i] = z0; Z[n + i] = z1; Z[2 * n + i] = z2;
                     const double yi = y[i];
                     YS[i] = yi + z0; YS[n + i] = yi + z1; YS[2 * n + i] = yi + z2;
@@ -368,7 +400,7 @@ __global__ void __launch_bounds__(WG_THREADS) radau_wg_kernel(RadauCtl* __restri
                 const double hstep = sc.h;
                 for (int64_t kk = tid; kk < n; kk += WG_THREADS) {
                     const int64_t i = to_field_major(kk, N);
-                    const double ZE = ((Z[i] * E0 + Z[n + i] * E1) + Z[2 * n + i] * E2) / hstep;
+                    const double ZE = dot3(Z[i], E0, Z[n + i], E1, Z[2 * n + i], E2) / hstep;
                     rhs_r[kk] = fvec[i] + ZE;
                     ynew[i] = y[i] + Z[2 * n + i];
                 }
@@ -382,7 +414,7 @@ __global__ void __launch_bounds__(WG_THREADS) radau_wg_kernel(RadauCtl* __restri
                     const double a = fabs(y[i]), bb = fabs(ynew[i]);
                     const double s = sc.atol + ((a > bb || a != a) ? a : bb) * sc.rtol;
                     const double q = e / s;
-                    ss += q * q;
+                    ss = __builtin_fma(q, q, ss);
                     err[i] = e;
                     yerr[i] = y[i] + e;
                 }

@@ -219,7 +219,7 @@ def test_radau_sweep_equals_instance_by_instance(torch_cuda_radau, oracle):
 @pytest.mark.parametrize("name", ["A", "matlab", "A_N64_tight"])
 def test_radau_fused_newton_launch_is_bit_identical(name):
     """Small systems (5 N <= 2048): the right-hand sides of both collocation systems, every cyclic-reduction level of both solves, the
-    update and the norm of a Newton iteration in ONE launch (radau::newton_fused_kernel, option radau_fused_solve = 2, the default)
+    update and the norm of a Newton iteration in ONE launch (radau::newton_fused_kernel, option radau_fused_solve = 2; not the default: measured slower)
     against the one-launch solves (1) and the per-level launches (0): the same arithmetic in the same order."""
     g, p, eq = _model(name)
     out = []
@@ -278,12 +278,14 @@ def test_radau_sweep_locates_event_roots_like_the_single_run(torch_cuda_radau):
             assert np.allclose(got.t_events[e], ref.t_events[e], rtol=0, atol=5e-4), (b, e, got.t_events[e], ref.t_events[e])
 
 
-def test_radau_sweep_wg_agrees_with_the_launch_path(torch_cuda_radau):
-    """Option radau_sweep_wg = 1: ONE persistent workgroup integrates an instance from start to end (marl_radau_wg.h; opt-in - measured
-    slower than the launch-per-action cycle so far).  Same step-logic function, restated kernel bodies: the two paths must
-    agree like two correct Radau runs - every instance reaches the end, statistics within 10 % (the complex multiply-adds of the
-    factorisation are contracted differently in the two contexts, and decisions at knife edges then fall either way), states within
-    the reference's own tolerance; on the short runs, where no decision has flipped yet, to 1e-9."""
+def test_radau_sweep_workgroup_paths_against_the_launch_path(torch_cuda_radau):
+    """Sweeps of small grids (option radau_sweep_wg): 1 = HYBRID, the default - one persistent workgroup per instance runs the sequential
+    work of the instance (step logic, Newton iterations, error estimates, accepted steps, event roots; marl_radau_wg.h) and hands it back to
+    the host cycle for Jacobians and factorisations (launch kernels over work lists); 2 = the workgroup does those too; 0 = one launch
+    cycle per action (round 2).  Same step-logic function everywhere.  HYBRID must reproduce the launch path's statistics EXACTLY and its
+    states to 1e-12 (same kernels for the factorisations, restated bodies with the same reduction trees for the rest); mode 2 inlines the
+    factorisation into the big kernel, where the compiler contracts its complex multiply-adds differently: it agrees like two correct
+    runs do (statistics within 10 %, states within the reference's tolerance; before any decision flips, to 1e-7)."""
     torch = torch_cuda_radau
     from dataclasses import asdict
     from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
@@ -294,7 +296,7 @@ def test_radau_sweep_wg_agrees_with_the_launch_path(torch_cuda_radau):
                 {"Phi0": 0.6, "PhiIni": 0.6, "PhiNR": 0.6}, {"Phi0": 0.65, "PhiIni": 0.5, "PhiNR": 0.5, "k3": 0.05, "k4": 0.05}]
         y0 = np.stack([np.concatenate([np.full(N, (base | d)[k]) for k in ("CAIni", "CCIni", "cCaIni", "cCO3Ini", "PhiIni")]) for d in inst])
         out = {}
-        for wg in (0, 1):
+        for wg in (0, 1, 2):
             eq = LMAHeureuxPorosityDiff.from_scenario(base, device=0, instances=inst)
             eq.use_stream(torch.cuda.current_stream().cuda_stream)
             eq.set_option("radau_sweep_wg", wg)
@@ -302,16 +304,18 @@ def test_radau_sweep_wg_agrees_with_the_launch_path(torch_cuda_radau):
             res = eq.sweep_radau_device(yd.data_ptr(), (0.0, t1), 1e-6, 1e-3, 1e-3, max_attempts=budget)
             out[wg] = (yd.cpu().numpy(), res)
             eq.close()
-        print(N, [(r.nfev, r.njev, r.nlu, r.n_accepted) for r in out[0][1]], [(r.nfev, r.njev, r.nlu, r.n_accepted) for r in out[1][1]])
+        print(N, [[(r.nfev, r.njev, r.nlu, r.n_accepted) for r in out[m][1]] for m in (0, 1, 2)])
         for b in range(len(inst)):
-            a, w = out[0][1][b], out[1][1][b]
-            assert a.status == w.status == (2 if budget else 0)
+            a, h, w = out[0][1][b], out[1][1][b], out[2][1][b]
+            assert a.status == h.status == w.status == (2 if budget else 0)
+            assert (a.nfev, a.njev, a.nlu, a.n_accepted, a.n_rejected, list(a.n_events)) == (h.nfev, h.njev, h.nlu, h.n_accepted, h.n_rejected, list(h.n_events)), (N, b)
+            assert a.t_reached == h.t_reached and np.max(np.abs(out[0][0][b] - out[1][0][b])) <= 1e-12, (N, b, float(np.max(np.abs(out[0][0][b] - out[1][0][b]))))
             for x, y in ((a.nfev, w.nfev), (a.njev, w.njev), (a.nlu, w.nlu), (a.n_accepted, w.n_accepted)):
                 assert abs(x - y) <= max(6, 0.1 * x), (N, b, x, y)
             if budget:
-                assert a.t_reached == pytest.approx(w.t_reached, rel=1e-6) and np.max(np.abs(out[0][0][b] - out[1][0][b])) <= 1e-7   # (observed 2e-9 / 1e-10 after 12 attempts)
+                assert a.t_reached == pytest.approx(w.t_reached, rel=1e-6) and np.max(np.abs(out[0][0][b] - out[2][0][b])) <= 1e-7   # (observed 2e-9 / 1e-10 after 12 attempts)
             else:
-                np.testing.assert_allclose(out[1][0][b], out[0][0][b], rtol=0.1, atol=0.01)
+                np.testing.assert_allclose(out[2][0][b], out[0][0][b], rtol=0.1, atol=0.01)
 
 
 def test_radau_sweep_of_512_scenarios_properties(torch_cuda_radau):
