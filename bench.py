@@ -560,6 +560,13 @@ def main():
             rs = eq.sweep_radau_device(yd.data_ptr(), (0.0, 1.0), 1e-6, 1e-3, 1e-3)
             sw = {"instances": Bs, "N": Ns, "seconds": time.perf_counter() - t0, "reached_Tstar": int(sum(r.status == 0 for r in rs)),
                   "nfev_median": float(np.median([r.nfev for r in rs])), "nfev_max": int(max(r.nfev for r in rs))}
+            # the same sweep WITH the monitors' root times located per instance (what the reference stores for every run)
+            yd = torch.from_numpy(y0).cuda()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rs = eq.sweep_radau_device(yd.data_ptr(), (0.0, 1.0), 1e-6, 1e-3, 1e-3, events=True, max_events=2048)
+            sw["seconds_with_event_roots"] = time.perf_counter() - t0
+            sw["event_roots_located"] = int(sum(len(t) for r in rs for t in r.t_events))
             eq.close()
             if rank == 0 and not args.no_cpu_baseline:
                 from oracle import oracle as orc

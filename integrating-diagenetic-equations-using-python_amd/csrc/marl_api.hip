@@ -2159,6 +2159,14 @@ int bdf_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_step
         LAUNCH_OK(ctx);
         if (n_equal_steps >= order + 1) {   // order / step-size selection (bdf.py:427-448); scale = atol + rtol |y_new| = |y| now
             double em = INFINITY, ep = INFINITY, ss;
+            if (order > 1 && order < MAX_ORDER && ctx->zc_on && radau_norm_blocks(n) == 1) {   // both norms: one launch, one wait
+                hipLaunchKernelGGL(bdf::scaled_norm2_kernel, dim3(1), dim3(1024), 0, ctx->stream, D + (int64_t)order * n, error_const[order - 1],
+                                   D + (int64_t)(order + 2) * n, error_const[order + 1], w.y, rtol, atol, n, w.out, ctx->zc_d + 3);
+                LAUNCH_OK(ctx);
+                if (int rc = radau_read(ctx, w, &ss, nullptr)) return rc;
+                em = std::sqrt(ss) / std::sqrt((double)n);
+                ep = std::sqrt(const_cast<const volatile double*>(ctx->zc_h)[3]) / std::sqrt((double)n);
+            } else {
             if (order > 1) {
                 if (int rc = bdf_scaled_sumsq(ctx, w, D + (int64_t)order * n, error_const[order - 1], w.y, rtol, atol, &ss)) return rc;
                 em = std::sqrt(ss) / std::sqrt((double)n);
@@ -2166,6 +2174,7 @@ int bdf_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_step
             if (order < MAX_ORDER) {
                 if (int rc = bdf_scaled_sumsq(ctx, w, D + (int64_t)(order + 2) * n, error_const[order + 1], w.y, rtol, atol, &ss)) return rc;
                 ep = std::sqrt(ss) / std::sqrt((double)n);
+            }
             }
             const double en[3] = {em, error_norm, ep};
             double factors[3];

@@ -195,6 +195,40 @@ __global__ void __launch_bounds__(1024) scaled_norm_kernel(const double* __restr
     if (threadIdx.x == 0) out[blockIdx.x] = red[0];
 }
 
+// The two error norms of the order selection (bdf.py:428-436: error_m from D[order], error_p from D[order + 2]) in ONE launch of one
+// workgroup - each with the loop and the reduction tree of scaled_norm_kernel (bit-identical), one launch and one wait less per selection.
+// out2 is written before out[0] (the word the host polls), with a system-scope fence in between.
+__global__ void __launch_bounds__(1024) scaled_norm2_kernel(const double* __restrict__ v1, double coef1, const double* __restrict__ v2, double coef2,
+                                                            const double* __restrict__ yref, double rtol, double atol, int64_t n, double* __restrict__ out,
+                                                            double* __restrict__ out2)
+{
+    __shared__ double red[1024];
+    double r[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const double* v = k ? v2 : v1;
+        const double coef = k ? coef2 : coef1;
+        double ss = 0;
+        for (int64_t i = threadIdx.x; i < n; i += 1024) {
+            const double e = coef * v[i] / (atol + rtol * fabs(yref[i]));
+            ss += e * e;
+        }
+        __syncthreads();
+        red[threadIdx.x] = ss;
+        __syncthreads();
+        for (int s = 512; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        r[k] = red[0];
+    }
+    if (threadIdx.x == 0) {
+        *out2 = r[1];
+        __threadfence_system();
+        out[0] = r[0];
+    }
+}
+
 // the accepted step's update of the differences (bdf.py:419-422); y = y_new
 __global__ void __launch_bounds__(256) accept_kernel(double* __restrict__ D, const double* __restrict__ d, const double* __restrict__ ynew, int64_t n, int order,
                                                      double* __restrict__ y)
