@@ -150,6 +150,8 @@ static void derive_consts(const marl_params& p, int64_t N, DevConsts& c, double 
     k.hdx = 0.5 * k.inv_dx;
     k.pe_smax = k.pe_cCa > k.pe_cCO3 ? k.pe_cCa : k.pe_cCO3;
     k.Dal = k.Da * k.lambda_;
+    k.Da_nu1 = k.Da * k.nu1;
+    k.Dal_nu2 = k.Dal * k.nu2;
     k.rr10 = 10.0 * k.rhorat;
     k.dPhi_dx2 = k.dPhi * k.inv_dx2;
     k.auxcon = auxcon;

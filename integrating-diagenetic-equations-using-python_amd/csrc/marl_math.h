@@ -45,6 +45,7 @@ struct HotConsts {
     double hdx;                      // 0.5/dx
     double pe_smax;                  // max(pe_cCa, pe_cCO3)
     double Dal;                      // Da * lambda_
+    double Da_nu1, Dal_nu2;          // Da * nu1, Da * lambda_ * nu2: the reaction prefactors folded into the saturation terms (tA, tC below)
     double rr10;                     // 10 * rhorat
     double dPhi_dx2;                 // dPhi / dx^2
     double auxcon;                   // :65-66 (the time-varying porosity diffusion coefficient, dPhi_variable)
@@ -267,10 +268,16 @@ struct PointLocal {
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wsometimes-uninitialized"  // den ... tA are set on exactly one of the two paths below
 // VD: the time-varying porosity diffusion coefficient (marl_params.dPhi_variable) - compiled in only where asked for.
-template <int MODE, int STRIDE, bool VD = false>
+// LEGACY: the operation order of rounds 1 - 2 (reaction prefactors applied after the products, F formed explicitly, (delta - c) differences).
+// The stand-alone RHS keeps it: the implicit path built on that RHS is pinned to scipy decision by decision, and a last-bit change of the
+// RHS flips Newton / step-size decisions.  The fused explicit integrators take the shorter forms (round 3: six
+// instructions less per evaluation - prefactors folded into the saturation terms, rhorat F and DaRi (delta - c) as one fma each, the
+// second-order reciprocal updates as x (1 - x) forms).
+template <int MODE, int STRIDE, bool VD = false, bool LEGACY = false>
 __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask, const HotConsts& K, const DevConsts* __restrict__ C,
                                             const Tables& T, PointLocal& pl, PointAux& aux, PointCache<STRIDE>& pc, bool& live)
 {
+    static_assert(!LEGACY || MODE == TR_PLAIN, "the legacy operation order is the stand-alone RHS's (no transcendental cache)");
 #ifdef MARL_ABLATE_CORE  // kernel-lab builds only: the skeleton (loads, LDS exchange, barriers, RK combinations)
     aux.U = aux.W = 0.0;
     return;
@@ -300,23 +307,26 @@ __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask
             const double e0 = pc.get(PC_E), tC0 = pc.get(PC_TC);
             const double x = d * invPhi0, y = d * invom0, u = dO * ib0;
             double l1p, ip, w, gy;
+            double da;                                                                    // change of 10 - 10/Phi = -10 (ip - invPhi0)
             if (tiny) {
                 l1p = x * __builtin_fma(x, -0.5, 1.0);                                    // log1p(x)
-                ip = invPhi0 * __builtin_fma(-x, 1.0 - x, 1.0);                           // 1/(Phi0 (1+x))
+                const double t10 = invPhi0 * __builtin_fma(-x, x, x);                     // invPhi0 x (1 - x)
+                ip = invPhi0 - t10;                                                       // 1/(Phi0 (1+x)) = invPhi0 (1 - x + x^2)
+                da = 10.0 * t10;
                 w = v * __builtin_fma(u, -0.5, 1.0);                                      // n log1p(u)
                 gy = __builtin_fma(y, 1.0 + y, 1.0);                                      // 1/(1-y)
             } else {
                 l1p = x * __builtin_fma(x, __builtin_fma(x, 1.0 / 3, -0.5), 1.0);
                 ip = invPhi0 * __builtin_fma(-x, __builtin_fma(-x, 1.0 - x, 1.0), 1.0);
+                da = -10.0 * (ip - invPhi0);
                 w = v * __builtin_fma(u, __builtin_fma(u, 1.0 / 3, -0.5), 1.0);
                 gy = __builtin_fma(y, __builtin_fma(y, 1.0 + y, 1.0), 1.0);
             }
             const double z = -2.0 * l1p * invden0;                                        // (den - den0)/den0
-            const double da = -10.0 * (ip - invPhi0);                                     // change of 10 - 10/Phi
             invPhi = ip;
             invom = invom0 * gy;
             if (tiny) {
-                invden = invden0 * __builtin_fma(-z, 1.0 - z, 1.0);
+                invden = __builtin_fma(-invden0, __builtin_fma(-z, z, z), invden0);       // invden0 (1 - z + z^2)
                 ex = e0 * __builtin_fma(da, __builtin_fma(da, 0.5, 1.0), 1.0);
                 tC = tC0 * __builtin_fma(w, __builtin_fma(w, 0.5, 1.0), 1.0);
             } else {
@@ -360,12 +370,12 @@ __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask
 #else
         const double pwC = pow_sat(fabs(O2 - 1.0), nsel, T);
 #endif
-        tC = (over ? 1.0 : -K.nu2) * pwC;
+        tC = (LEGACY ? (over ? 1.0 : -K.nu2) : (over ? K.Dal : -K.Dal_nu2)) * pwC;   // (the prefactor Da lambda of the calcite term rides along: DC = CC tC below)
         if (K.generic_p0) {  // an exponent <= 0: pow(0, e) is 1 or inf instead of 0 (rare; constants from memory)
             asm volatile("");  // keep this a (uniform) branch: if-converted, its arithmetic would run on every evaluation
-            const double y1 = C->p0_n1, y2 = C->p0_n2;
+            const double y1 = C->p0_n1, y2 = C->p0_n2, nu2 = C->hot.nu2;
             const double pcw = (O2 == 1.0) ? (over ? y1 : y2) : pwC;
-            tC = over ? pcw - K.nu2 * y2 : y1 - K.nu2 * pcw;
+            tC = (LEGACY ? 1.0 : K.Dal) * (over ? pcw - nu2 * y2 : y1 - nu2 * pcw);
         }
         if constexpr (MODE == TR_FILL || MODE == TR_AUTO) {
             // generic_p0 (an exponent < 1 or <= 0: the clamp-pair shortcut / the bound |u| <= |n u| do not hold): never reuse
@@ -386,18 +396,17 @@ __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask
         tA = O3 - O3;                               // 0, or NaN for a non-finite O3 (keeps the reference's NaN visible)
         if (!under || in_mask) {
             const double pwA = pow_sat(fabs(O3 - 1.0), under ? K.m2 : K.m1, T);
-            tA = (under ? 1.0 : -K.nu1) * pwA;      // (1-O3)^m2 * mask  |  -nu1 (O3-1)^m1
+            tA = (LEGACY ? (under ? 1.0 : -K.nu1) : (under ? K.Da : -K.Da_nu1)) * pwA;  // [Da] ((1-O3)^m2 * mask  |  -nu1 (O3-1)^m1): DA = CA tA below
         }
         if (K.generic_p0) {
             asm volatile("");  // a real branch, as above
-            const double z1 = C->p0_m1, z2 = C->p0_m2;
+            const double z1 = C->p0_m1, z2 = C->p0_m2, nu1 = C->hot.nu1;
             const double mask = in_mask ? 1.0 : 0.0;
             const double pa = (O3 == 1.0) ? (under ? z2 : z1) : ((!under || in_mask) ? fast_exp((under ? K.m2 : K.m1) * fast_log(fabs(O3 - 1.0), T), T) : 0.0);
-            tA = under ? pa * mask - K.nu1 * z1 : z2 * mask - K.nu1 * pa;
+            tA = (LEGACY ? 1.0 : K.Da) * (under ? pa * mask - nu1 * z1 : z2 * mask - nu1 * pa);
         }
     }
-    const double F = 1.0 - ex;
-    const double rF = K.rhorat * F;
+    const double rF = LEGACY ? K.rhorat * (1.0 - ex) : __builtin_fma(-K.rhorat, ex, K.rhorat);   // rhorat F,  F = 1 - exp(10 - 10/Phi)
     const double t2 = rF * (Phi * Phi);
     const double W = K.presum - t2;
     const double U = __builtin_fma(t2 * Phi, invom, K.presum);
@@ -405,13 +414,13 @@ __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask
     aux.W = W;
     double wpe = fabs(W) * K.pe_Phi;   // |Peclet_Phi| (:452)
     if constexpr (VD) {   // dPhi = auxcon F Phi^3/(1-Phi) (:430, commented out in the reference) instead of dPhi_fixed
-        const double dPhi = K.auxcon * (F * (Phi * Phi)) * (Phi * invom);
+        const double dPhi = K.auxcon * ((1.0 - ex) * (Phi * Phi)) * (Phi * invom);
         wpe = fabs(W) * (K.pe_Phi * (K.dPhi * rcp_nr(dPhi)));   // delta_x / (2 dPhi)
     }
 
     // ---- reaction terms (:479-493)
-    const double DA = K.Da * (CA * tA);          // Da coA
-    const double DC = K.Dal * (CC * tC);         // Da lambda coC
+    const double DA = LEGACY ? K.Da * (CA * tA) : CA * tA;     // Da coA         (tA, tC carry Da / Da lambda unless LEGACY)
+    const double DC = LEGACY ? K.Dal * (CC * tC) : CC * tC;    // Da lambda coC
     const double DmD = DA - DC;
     const double DaR = omPhi * DmD;              // Da (1-Phi) (coA - lambda coC)
     // solids (:498-503): (1-CA) DA + CA DC = DA - CA (DA - DC);  CC DA + (1-CC) DC = DC + CC (DA - DC)
@@ -437,8 +446,14 @@ __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask
     pl.W = W;
     pl.invPhi = invPhi;
     const double DaRi = DaR * invPhi;
-    pl.G2 = DaRi * (K.delta - c);                                   // :506-509, :512-515
-    pl.G3 = DaRi * (K.delta - o);
+    if constexpr (LEGACY) {
+        pl.G2 = DaRi * (K.delta - c);                               // :506-509, :512-515
+        pl.G3 = DaRi * (K.delta - o);
+    } else {
+        const double Dd = DaRi * K.delta;
+        pl.G2 = __builtin_fma(-DaRi, c, Dd);                        // DaRi (delta - c)
+        pl.G3 = __builtin_fma(-DaRi, o, Dd);
+    }
     pl.h1x = (Phi * invden) * K.inv_dx2;                            // Phi/den / dx^2
     pl.h2f = invden * __builtin_fma(2.0, invden, 1.0);              // (2+den)/den^2
     const double q = __builtin_fma(rF, __builtin_fma(2.0, Phi, 10.0), -K.rr10);  // rhorat (2 Phi F + 10 (F-1))  (:495)
@@ -516,7 +531,7 @@ __device__ __forceinline__ void rhs_point(const double (&uc)[NF], const double (
                                           const Tables& T, double (&r)[NF], PointAux& aux, PointCache<STRIDE>& pc, bool& live)
 {
     PointLocal pl;
-    point_local<MODE, STRIDE, VD>(uc, in_mask, K, C, T, pl, aux, pc, live);
+    point_local<MODE, STRIDE, VD, true>(uc, in_mask, K, C, T, pl, aux, pc, live);   // (LEGACY operation order: see point_local)
     point_rates<VD, false>(uc, um, up, K, T, pl, r);
 }
 
