@@ -15,6 +15,7 @@
 #include "../../include/marl_hip.h"
 #include "marl_kernels.h"
 #include "marl_radau.h"
+#include "marl_radau_cr.h"
 #include "marl_radau_batch.h"
 #include "marl_radau_wg.h"
 #include "marl_bdf.h"
@@ -83,6 +84,9 @@ struct marl_ctx {
     int64_t implicit_zero_copy = 1;  // scalar results of the implicit drivers through polled host memory (0: copy + synchronise)
     int64_t radau_fused_solve = 1;   // small systems (5 N <= 2048): 1 = all PCR levels of a solve in one launch (BDF: the whole Newton iteration); 2 = Radau too: the whole iteration's linear algebra in one launch (bit-identical, measured SLOWER: 10.1 vs 9.0 ms - the two solves then run one after the other)
     int64_t radau_solver = 0;   // 0: block parallel cyclic reduction (parallel over depth); 1: sequential block Thomas
+    int64_t radau_cr = -1;      // single runs: levels of cyclic reduction in front of PCR; -1 = automatic (grids of >= radau_cr_min_n cells: down to a
+                                // compact system that fits the one-launch solve), 0 = none
+    int64_t radau_cr_min_n = 2048;
     int64_t radau_sweep_wg = 1; // sweeps of small grids: 1 hybrid (workgroup per instance for the sequential work, launch kernels for Jacobians / factorisations), 2 all in the workgroup, 0 launch per action
     std::string err;
 };
@@ -327,6 +331,8 @@ int marl_set_option(marl_ctx* ctx, const char* name, int64_t value)
     else if (n == "host_layout") ctx->host_layout = value ? LAYOUT_TILED : LAYOUT_FIELD_MAJOR;
     else if (n == "poll_interval") ctx->poll = value > 0 ? value : 1;
     else if (n == "radau_solver") ctx->radau_solver = value ? 1 : 0;
+    else if (n == "radau_cr") ctx->radau_cr = (value < 0) ? -1 : std::min<int64_t>(value, radau::CR_MAX_LEVELS);
+    else if (n == "radau_cr_min_n") ctx->radau_cr_min_n = std::max<int64_t>(value, 4);
     else if (n == "radau_fused_solve") ctx->radau_fused_solve = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "radau_sweep_wg") ctx->radau_sweep_wg = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "implicit_zero_copy") ctx->implicit_zero_copy = value ? 1 : 0;
@@ -1392,6 +1398,12 @@ struct RadauWork {
     radau::PcrSystem<cplx> Sc{};
     int nlevels = 0;
     bool pcr = true;
+    // cyclic reduction in front of it (marl_radau_cr.h; large grids of single runs): cr_k levels, level l has cr_n[l] rows stored from row
+    // cr_off[l]; Sr / Sc / nlevels then describe the COMPACT system of the cr_n[cr_k] rows that are left
+    int cr_k = 0;
+    int64_t cr_n[radau::CR_MAX_LEVELS + 1] = {}, cr_off[radau::CR_MAX_LEVELS + 2] = {};
+    radau::CrSystem<double> Cr{};
+    radau::CrSystem<cplx> Cc{};
 };
 
 // Zero-copy slots: arm = store the sentinel; wait = poll until the kernel has overwritten it (bounded, then fall back to a synchronise).
@@ -1439,10 +1451,25 @@ int radau_alloc(marl_ctx* ctx, RadauWork& w, const int32_t* groups_host, int64_t
                 if (j2 != j && g[j2] == g[j]) return fail(ctx, -1, "radau: columns %lld and %lld share rows but are in one group", (long long)j, (long long)j2);
             }
     }
+    // cyclic-reduction levels in front of PCR (single runs with the PCR solver only)
+    w.cr_k = 0;
+    w.cr_n[0] = N; w.cr_off[0] = 0;
+    if (instances == 1 && ctx->radau_solver == 0 && ctx->radau_cr != 0 && (ctx->radau_cr > 0 || N >= ctx->radau_cr_min_n)) {
+        int k = 0;
+        while (k < radau::CR_MAX_LEVELS && w.cr_n[k] / 2 >= 2 && (ctx->radau_cr > 0 ? k < ctx->radau_cr : NF * w.cr_n[k] > radau::PCR_FUSED_MAX)) {
+            w.cr_n[k + 1] = w.cr_n[k] / 2;
+            w.cr_off[k + 1] = w.cr_off[k] + w.cr_n[k];
+            k++;
+        }
+        w.cr_k = k;
+    }
+    const int64_t M = w.cr_n[w.cr_k];                                      // rows of the system PCR works on
+    const int64_t cr_rows = w.cr_k ? w.cr_off[w.cr_k] + M : 0;             // rows of all levels together (< 2 N)
     int nlev = 0;
-    while (((int64_t)1 << nlev) < N) nlev++;
-    const size_t pcr_real = (size_t)N * 25 * (8 + 2 * (size_t)nlev) + 2 * (size_t)n;   // L, D, U, Dinv ping-pong; alpha, gamma per level; b ping-pong
-    const size_t doubles = (size_t)n * (9 + 6 * 3 + 6 + 15 + 2 * (size_t)ng + 15 + 10 + 20 + 1 + 2) + 64 + kRadauPartials + (size_t)n + 3 * pcr_real;
+    while (((int64_t)1 << nlev) < M) nlev++;
+    const size_t pcr_real = (size_t)M * 25 * (8 + 2 * (size_t)nlev) + 2 * (size_t)NF * M;   // L, D, U, Dinv ping-pong; alpha, gamma per level; b ping-pong
+    const size_t cr_real = (size_t)cr_rows * (8 * 25 + NF);                             // L, D, U, Dinv, P, Q, alpha, gamma; b
+    const size_t doubles = (size_t)n * (9 + 6 * 3 + 6 + 15 + 2 * (size_t)ng + 15 + 10 + 20 + 1 + 2) + 64 + kRadauPartials + (size_t)n + 3 * pcr_real + 3 * cr_real;
     const size_t per = (doubles + 1) & ~(size_t)1;   // 16-byte multiples: complex members stay aligned in every instance
     if (zstride) *zstride = (int64_t)(per * sizeof(double));
     if (ctx->rd_cap < per * (size_t)instances) {
@@ -1479,12 +1506,19 @@ int radau_alloc(marl_ctx* ctx, RadauWork& w, const int32_t* groups_host, int64_t
     w.nlevels = nlev;
     w.pcr = ctx->radau_solver == 0;
     for (int k = 0; k < 2; k++) {
-        w.Sr.L[k] = take(25 * N); w.Sr.D[k] = take(25 * N); w.Sr.U[k] = take(25 * N); w.Sr.Dinv[k] = take(25 * N); w.Sr.b[k] = take(n);
-        w.Sc.L[k] = (cplx*)take(50 * N); w.Sc.D[k] = (cplx*)take(50 * N); w.Sc.U[k] = (cplx*)take(50 * N); w.Sc.Dinv[k] = (cplx*)take(50 * N);
-        w.Sc.b[k] = (cplx*)take(2 * n);
+        w.Sr.L[k] = take(25 * M); w.Sr.D[k] = take(25 * M); w.Sr.U[k] = take(25 * M); w.Sr.Dinv[k] = take(25 * M); w.Sr.b[k] = take(NF * M);
+        w.Sc.L[k] = (cplx*)take(50 * M); w.Sc.D[k] = (cplx*)take(50 * M); w.Sc.U[k] = (cplx*)take(50 * M); w.Sc.Dinv[k] = (cplx*)take(50 * M);
+        w.Sc.b[k] = (cplx*)take(2 * NF * M);
     }
-    w.Sr.alpha = take((size_t)nlev * 25 * N); w.Sr.gamma = take((size_t)nlev * 25 * N);
-    w.Sc.alpha = (cplx*)take((size_t)nlev * 50 * N); w.Sc.gamma = (cplx*)take((size_t)nlev * 50 * N);
+    w.Sr.alpha = take((size_t)nlev * 25 * M); w.Sr.gamma = take((size_t)nlev * 25 * M);
+    w.Sc.alpha = (cplx*)take((size_t)nlev * 50 * M); w.Sc.gamma = (cplx*)take((size_t)nlev * 50 * M);
+    if (w.cr_k) {
+        const size_t R = (size_t)cr_rows;
+        double** pr[8] = {&w.Cr.L, &w.Cr.D, &w.Cr.U, &w.Cr.Dinv, &w.Cr.P, &w.Cr.Q, &w.Cr.alpha, &w.Cr.gamma};
+        cplx** pc[8] = {&w.Cc.L, &w.Cc.D, &w.Cc.U, &w.Cc.Dinv, &w.Cc.P, &w.Cc.Q, &w.Cc.alpha, &w.Cc.gamma};
+        for (int a = 0; a < 8; a++) { *pr[a] = take(25 * R); *pc[a] = (cplx*)take(50 * R); }
+        w.Cr.b = take(NF * R); w.Cc.b = (cplx*)take(2 * NF * R);
+    }
     if (instances > 1) HIP_OK(ctx, hipMemsetAsync(ctx->rd_arena, 0, per * (size_t)instances * sizeof(double), ctx->stream));
     else HIP_OK(ctx, hipMemsetAsync(w.J, 0, sizeof(double) * 15 * n, ctx->stream));
     HIP_OK(ctx, hipMemcpyAsync(w.groups, g.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));   // (one copy serves every instance)
@@ -1496,6 +1530,63 @@ inline unsigned blocks256(int64_t n) { return (unsigned)((n + 255) / 256); }
 // workgroups of the norm kernels: one up to 8192 unknowns, then one per 4096, at most kRadauPartials
 inline int radau_norm_blocks(int64_t n) { return n <= 8192 ? 1 : (int)std::min<int64_t>(256, (n + 4095) / 4096); }
 
+inline unsigned pcr_groups(int64_t rows) { return (unsigned)((rows + radau::PCR_CELLS_PER_BLOCK - 1) / radau::PCR_CELLS_PER_BLOCK); }
+
+// factorise  mu I - jscale J  for the real system (systems = 1) or the real and the complex one (2): block PCR over all N rows
+// (1 + ceil(log2 N) launches), or - large grids of single runs - cr_k levels of cyclic reduction and PCR over the rows that are left
+int pcr_factor_launch(marl_ctx* ctx, RadauWork& w, double mu_r, cplx mu_c, double jscale, int systems)
+{
+    const int64_t N = ctx->N;
+    const ZBatch none{0, nullptr, 0, 0, nullptr};
+    if (!w.cr_k) {
+        const dim3 grid(pcr_groups(N), systems);
+        for (int level = -1; level < w.nlevels; level++) {
+            hipLaunchKernelGGL(radau::pcr_factor_kernel, grid, dim3(256), 0, ctx->stream, w.J, N, level, mu_r, mu_c, w.Sr, w.Sc, none, jscale);
+            LAUNCH_OK(ctx);
+        }
+        return 0;
+    }
+    hipLaunchKernelGGL(radau::cr_init_kernel, dim3(pcr_groups((N + 1) / 2), systems), dim3(256), 0, ctx->stream, w.J, N, mu_r, mu_c, jscale, w.Cr, w.Cc);
+    LAUNCH_OK(ctx);
+    for (int l = 0; l < w.cr_k; l++) {
+        const radau::CrShape sh{w.cr_n[l], w.cr_off[l], w.cr_n[l + 1], w.cr_off[l + 1]};
+        hipLaunchKernelGGL(radau::cr_reduce_kernel, dim3(pcr_groups(sh.n_next), systems), dim3(256), 0, ctx->stream, mu_r, mu_c, w.Cr, w.Cc, sh,
+                           l + 1 == w.cr_k ? 1 : 0, w.Sr, w.Sc);
+        LAUNCH_OK(ctx);
+    }
+    const int64_t M = w.cr_n[w.cr_k];
+    for (int level = 0; level < w.nlevels; level++) {   // (level -1 - blocks from J and their inverses - is what the last reduction left in set 0)
+        hipLaunchKernelGGL(radau::pcr_factor_kernel, dim3(pcr_groups(M), systems), dim3(256), 0, ctx->stream, w.J, M, level, mu_r, mu_c, w.Sr, w.Sc, none, jscale);
+        LAUNCH_OK(ctx);
+    }
+    return 0;
+}
+
+// PCR solve of M rows, in place in x_r (and, with `both`, x_c)
+int pcr_solve_launch(marl_ctx* ctx, RadauWork& w, int64_t M, bool both, double* x_r, cplx* x_c)
+{
+    const int64_t n = NF * M;
+    if (n <= radau::PCR_FUSED_MAX && ctx->radau_fused_solve) {   // small systems: every level in one launch
+        hipLaunchKernelGGL(radau::pcr_solve_fused_kernel, dim3(1, both ? 2 : 1), dim3(radau::PCR_FUSED_THREADS), 0, ctx->stream, M, w.nlevels, 0, w.Sr, w.Sc,
+                           x_r, x_r, x_c, x_c);
+        LAUNCH_OK(ctx);
+        return 0;
+    }
+    const dim3 grid(blocks256(n), both ? 2 : 1);
+    // ping-pong: x -> b[0] -> b[1] -> ... ; the last launch (x = D^-1 b) writes back into x
+    const double* in_r = x_r;
+    const cplx* in_c = x_c;
+    for (int level = 0; level <= w.nlevels; level++) {
+        double* out_r = (level == w.nlevels) ? x_r : w.Sr.b[level & 1];
+        cplx* out_c = (level == w.nlevels) ? x_c : w.Sc.b[level & 1];
+        hipLaunchKernelGGL(radau::pcr_solve_kernel, grid, dim3(256), 0, ctx->stream, M, level, w.nlevels, 0, w.Sr, w.Sc, in_r, out_r, in_c, out_c);
+        LAUNCH_OK(ctx);
+        in_r = out_r;
+        in_c = out_c;
+    }
+    return 0;
+}
+
 // factorise  mu_r I - J  and  mu_c I - J  (block PCR: 1 + ceil(log2 N) launches; or sequential block Thomas: 1 launch)
 int radau_factor(marl_ctx* ctx, RadauWork& w, double mu_r, cplx mu_c)
 {
@@ -1505,41 +1596,34 @@ int radau_factor(marl_ctx* ctx, RadauWork& w, double mu_r, cplx mu_c)
         LAUNCH_OK(ctx);
         return 0;
     }
-    const dim3 grid((unsigned)((N + radau::PCR_CELLS_PER_BLOCK - 1) / radau::PCR_CELLS_PER_BLOCK), 2);
-    for (int level = -1; level < w.nlevels; level++) {
-        hipLaunchKernelGGL(radau::pcr_factor_kernel, grid, dim3(256), 0, ctx->stream, w.J, N, level, mu_r, mu_c, w.Sr, w.Sc);
-        LAUNCH_OK(ctx);
-    }
-    return 0;
+    return pcr_factor_launch(ctx, w, mu_r, mu_c, 1.0, 2);
 }
 
 // solve in place: w.rhs_r (and, with `both`, w.rhs_c), cell-major
 int radau_solve(marl_ctx* ctx, RadauWork& w, bool both)
 {
-    const int64_t N = ctx->N, n = NF * N;
+    const int64_t N = ctx->N;
     if (!w.pcr) {
         hipLaunchKernelGGL(radau::solve_kernel, dim3(both ? 2 : 1), dim3(64), 0, ctx->stream, w.J, N, w.Dinv_r, w.Up_r, w.Dinv_c, w.Up_c, w.rhs_r, w.rhs_c,
                            both ? 3 : 1);
         LAUNCH_OK(ctx);
         return 0;
     }
-    if (n <= radau::PCR_FUSED_MAX && ctx->radau_fused_solve) {   // small systems: every level in one launch
-        hipLaunchKernelGGL(radau::pcr_solve_fused_kernel, dim3(1, both ? 2 : 1), dim3(radau::PCR_FUSED_THREADS), 0, ctx->stream, N, w.nlevels, 0, w.Sr, w.Sc,
-                           w.rhs_r, w.rhs_r, w.rhs_c, w.rhs_c);
+    if (!w.cr_k) return pcr_solve_launch(ctx, w, N, both, w.rhs_r, w.rhs_c);
+    // right-hand sides down the reduction levels, the compact system by PCR, solutions back up (in place from level to level)
+    const unsigned gy = both ? 2 : 1;
+    for (int l = 0; l < w.cr_k; l++) {
+        const radau::CrShape sh{w.cr_n[l], w.cr_off[l], w.cr_n[l + 1], w.cr_off[l + 1]};
+        hipLaunchKernelGGL(radau::cr_rhs_kernel, dim3(blocks256(NF * sh.n_next), gy), dim3(256), 0, ctx->stream, w.Cr, w.Cc, sh, l, w.rhs_r, w.rhs_c);
         LAUNCH_OK(ctx);
-        return 0;
     }
-    const dim3 grid(blocks256(n), both ? 2 : 1);
-    // ping-pong: rhs -> b[0] -> b[1] -> ... ; the last launch (x = D^-1 b) writes back into rhs
-    const double* in_r = w.rhs_r;
-    const cplx* in_c = w.rhs_c;
-    for (int level = 0; level <= w.nlevels; level++) {
-        double* out_r = (level == w.nlevels) ? w.rhs_r : w.Sr.b[level & 1];
-        cplx* out_c = (level == w.nlevels) ? w.rhs_c : w.Sc.b[level & 1];
-        hipLaunchKernelGGL(radau::pcr_solve_kernel, grid, dim3(256), 0, ctx->stream, N, level, w.nlevels, 0, w.Sr, w.Sc, in_r, out_r, in_c, out_c);
+    const int64_t offk = w.cr_off[w.cr_k];
+    if (int rc = pcr_solve_launch(ctx, w, w.cr_n[w.cr_k], both, w.Cr.b + offk * NF, w.Cc.b + offk * NF)) return rc;
+    for (int l = w.cr_k - 1; l >= 0; l--) {
+        const radau::CrShape sh{w.cr_n[l], w.cr_off[l], w.cr_n[l + 1], w.cr_off[l + 1]};
+        hipLaunchKernelGGL(radau::cr_back_kernel, dim3((unsigned)((sh.n_cur + radau::CR_ROWS_PER_BLOCK - 1) / radau::CR_ROWS_PER_BLOCK), gy),
+                           dim3(radau::CR_ROWS_PER_BLOCK * NF), 0, ctx->stream, w.Cr, w.Cc, sh, l, w.rhs_r, w.rhs_c);
         LAUNCH_OK(ctx);
-        in_r = out_r;
-        in_c = out_c;
     }
     return 0;
 }
@@ -1760,7 +1844,7 @@ int radau_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_st
                 for (k = 0; k < NEWTON_MAXITER; k++) {
                     if (int rc = launch_rhs(ctx, w.YS, w.F, LAYOUT_FIELD_MAJOR, 3)) return rc;
                     st->nfev += 3;
-                    if (w.pcr && n <= radau::PCR_FUSED_MAX && ctx->radau_fused_solve >= 2) {   // right-hand sides + both solves + update + norm: one launch
+                    if (w.pcr && !w.cr_k && n <= radau::PCR_FUSED_MAX && ctx->radau_fused_solve >= 2) {   // right-hand sides + both solves + update + norm: one launch
                         hipLaunchKernelGGL(radau::newton_fused_kernel, dim3(1), dim3(radau::PCR_FUSED_THREADS), 0, ctx->stream, w.y, w.F, N, M_real, M_c, w.nlevels, w.Sr,
                                            w.Sc, w.scale, w.W, w.Z, w.YS, w.rhs_r, w.rhs_c, w.flags, w.out);
                         LAUNCH_OK(ctx);
@@ -2065,11 +2149,7 @@ int bdf_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_step
             bool first_pass = true;
             while (!converged) {
                 if (!have_lu) {   // LU = self.lu(self.I - c * J)
-                    for (int level = -1; level < w.nlevels; level++) {
-                        hipLaunchKernelGGL(radau::pcr_factor_kernel, dim3((unsigned)((N + radau::PCR_CELLS_PER_BLOCK - 1) / radau::PCR_CELLS_PER_BLOCK), 1), dim3(256),
-                                           0, ctx->stream, w.J, N, level, 1.0, cplx{0, 0}, w.Sr, w.Sc, ZBatch{0, nullptr, 0, 0, nullptr}, c);
-                        LAUNCH_OK(ctx);
-                    }
+                    if (int rc = pcr_factor_launch(ctx, w, 1.0, cplx{0, 0}, c, 1)) return rc;
                     st->nlu++;
                     have_lu = true;
                 }
@@ -2084,7 +2164,7 @@ int bdf_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_step
                 for (k = 0; k < NEWTON_MAXITER; k++) {
                     if (int rc = launch_rhs(ctx, w.ynew, f, LAYOUT_FIELD_MAJOR)) return rc;
                     st->nfev++;
-                    if (n <= radau::PCR_FUSED_MAX && ctx->radau_fused_solve) {   // right-hand side + every level + update + norm in one launch
+                    if (!w.cr_k && n <= radau::PCR_FUSED_MAX && ctx->radau_fused_solve) {   // right-hand side + every level + update + norm in one launch
                         // (with the zero-copy result words: the step's local error norm rides along - bdf.py:398-400 - one launch and
                         //  one wait less per step)
                         fused_err = ctx->zc_on;

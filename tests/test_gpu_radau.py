@@ -148,6 +148,51 @@ def test_radau_api_errors_and_budget(oracle):
     eq.close()
 
 
+@pytest.mark.parametrize("method", ["radau", "bdf"])
+def test_cyclic_reduction_front_end_on_the_reference_grid_walks_scipys_decisions(method):
+    """Large grids of single runs put levels of block cyclic reduction in front of PCR (csrc/marl_radau_cr.h; automatic from 2048 cells).
+    Forced onto the reference's N = 200 grid (3 levels: 200 -> 100 -> 50 -> 25 rows, PCR on the 25), the run must still make every
+    decision scipy makes on the reference's RHS - same nfev / njev / nlu / steps as the goldens - and land on PCR's state to far below
+    the solver tolerance (the rows that stay see PCR's arithmetic; the eliminated ones differ in rounding)."""
+    g, p, eq = _model("A")
+    run = eq.integrate_radau if method == "radau" else eq.integrate_bdf
+    gold = g if method == "radau" else np.load(f"{GOLDEN}/bdf_traj_A.npz")
+    out = []
+    for cr in (0, 3):
+        eq.set_option("radau_cr", cr)
+        out.append(run(g["y0"], tuple(g["t_span"]), float(g["first_step"]), float(g["rtol"]), float(g["atol"])))
+    eq.close()
+    a, b = out
+    assert a.status == b.status == 0
+    want = (int(gold["nfev"]), int(gold["njev"]), int(gold["nlu"]), len(gold["step_times"]) - 1)
+    assert (a.nfev, a.njev, a.nlu, a.n_accepted) == want
+    assert (b.nfev, b.njev, b.nlu, b.n_accepted) == want
+    assert np.max(np.abs(a.y_final - b.y_final)) < 2e-5        # observed 2.2e-6 (Radau), 2.2e-7 (BDF)
+    for ea, eb in zip(a.t_events, b.t_events):
+        assert len(ea) == len(eb) and np.allclose(ea, eb, rtol=0, atol=1e-6)
+
+
+def test_cyclic_reduction_front_end_against_pcr_and_the_oracle_at_4000_cells(oracle):
+    """N = 4000 (automatic: 4 levels down to 250 rows, then the one-launch PCR solve): the statistics of the run equal plain PCR's and the
+    oracle's (banded LU on the CPU), the states agree within the solver's tolerance."""
+    from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
+    N = 4000
+    p = scenario("A", N)
+    y0 = np.concatenate([np.full(N, p[k]) for k in ("CAIni", "CCIni", "cCaIni", "cCO3Ini", "PhiIni")])
+    eq = LMAHeureuxPorosityDiff.from_scenario(p, device=0)
+    out = []
+    for cr in (0, -1):
+        eq.set_option("radau_cr", cr)
+        out.append(eq.integrate_radau(y0, (0.0, 1.0), 1e-6, 1e-3, 1e-3))
+    eq.close()
+    a, b = out
+    y, st, *_ = oracle.radau(oracle.params_from_dict(p), N, y0, 0.0, 1.0, 1e-6, 1e-3, 1e-3)
+    assert a.status == b.status == st.status == 0
+    assert (a.nfev, a.njev, a.nlu, a.n_accepted) == (st.nfev, st.njev, st.nlu, st.n_accepted)
+    assert (b.nfev, b.njev, b.nlu, b.n_accepted) == (st.nfev, st.njev, st.nlu, st.n_accepted)
+    assert np.max(np.abs(b.y_final - y)) < 1e-3 and np.max(np.abs(a.y_final - y)) < 1e-3      # observed 2.2e-4, 4.6e-5 (rtol = atol = 1e-3)
+
+
 @pytest.mark.parametrize("name", ["A", "matlab"])
 def test_radau_fused_solve_is_bit_identical_to_per_level_solve(oracle, name):
     """Small systems (5 N <= 2048) run all levels of a PCR solve in one launch (pcr_solve_fused_kernel: right-hand side in LDS, a

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The implicit (Radau / BDF) path as a profiling target:  rocprofv3 --kernel-trace --stats -- python3 tools/radau_profile.py [what ...]
-what: single (Scenario A to T* at N = 200, 16 000, 64 000), bdf (the same at N = 200 with BDF), sweep (512 scenarios, N = 200).
+what: single (Scenario A to T* at N = 200, 16 000, 64 000; MARL_RADAU_NS=64000 picks other sizes), bdf (the same at N = 200 with BDF),
+sweep (512 scenarios, N = 200).
 Prints wall times; the kernel statistics / counters come from the profiler around it (tools/profile_round.sh)."""
 import os
 import sys
@@ -23,7 +24,8 @@ def y0_of(p, N):
 
 if "single" in what or "bdf" in what:
     for method in [m for m in ("single", "bdf") if m in what]:
-        for N in ((200, 16000, 64000) if method == "single" else (200,)):
+        sizes = [int(x) for x in os.environ["MARL_RADAU_NS"].split(",")] if os.environ.get("MARL_RADAU_NS") else None
+        for N in sizes or ((200, 16000, 64000) if method == "single" else (200,)):
             p = scenario("A", N)
             eq = LMAHeureuxPorosityDiff.from_scenario(p, device=0)
             run = eq.integrate_radau if method == "single" else eq.integrate_bdf
