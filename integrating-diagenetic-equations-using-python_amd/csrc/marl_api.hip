@@ -85,7 +85,7 @@ struct marl_ctx {
     int64_t radau_fused_solve = 1;   // small systems (5 N <= 2048): 1 = all PCR levels of a solve in one launch (BDF: the whole Newton iteration); 2 = Radau too: the whole iteration's linear algebra in one launch (bit-identical, measured SLOWER: 10.1 vs 9.0 ms - the two solves then run one after the other)
     int64_t radau_solver = 0;   // 0: block parallel cyclic reduction (parallel over depth); 1: sequential block Thomas
     int64_t radau_cr = -1;      // single runs: levels of cyclic reduction in front of PCR; -1 = automatic (grids of >= radau_cr_min_n cells: down to a
-                                // compact system that fits the one-launch solve), 0 = none
+                                // compact system that fits the one-launch solve with one unknown per thread), 0 = none
     int64_t radau_cr_min_n = 2048;
     int64_t radau_sweep_wg = 1; // sweeps of small grids: 1 hybrid (workgroup per instance for the sequential work, launch kernels for Jacobians / factorisations), 2 all in the workgroup, 0 launch per action
     std::string err;
@@ -1456,7 +1456,7 @@ int radau_alloc(marl_ctx* ctx, RadauWork& w, const int32_t* groups_host, int64_t
     w.cr_n[0] = N; w.cr_off[0] = 0;
     if (instances == 1 && ctx->radau_solver == 0 && ctx->radau_cr != 0 && (ctx->radau_cr > 0 || N >= ctx->radau_cr_min_n)) {
         int k = 0;
-        while (k < radau::CR_MAX_LEVELS && w.cr_n[k] / 2 >= 2 && (ctx->radau_cr > 0 ? k < ctx->radau_cr : NF * w.cr_n[k] > radau::PCR_FUSED_MAX)) {
+        while (k < radau::CR_MAX_LEVELS && w.cr_n[k] / 2 >= 2 && (ctx->radau_cr > 0 ? k < ctx->radau_cr : NF * w.cr_n[k] > radau::PCR_FUSED_THREADS)) {
             w.cr_n[k + 1] = w.cr_n[k] / 2;
             w.cr_off[k + 1] = w.cr_off[k] + w.cr_n[k];
             k++;
