@@ -87,6 +87,7 @@ struct marl_ctx {
     int64_t radau_cr = -1;      // single runs: levels of cyclic reduction in front of PCR; -1 = automatic (grids of >= radau_cr_min_n cells: down to a
                                 // compact system that fits the one-launch solve with one unknown per thread), 0 = none
     int64_t radau_cr_min_n = 2048;
+    int64_t radau_cr_tail = 1;  // the launch-bound levels of a cyclic-reduction solve in one launch each way (0: one launch per level)
     int64_t radau_sweep_wg = 1; // sweeps of small grids: 1 hybrid (workgroup per instance for the sequential work, launch kernels for Jacobians / factorisations), 2 all in the workgroup, 0 launch per action
     std::string err;
 };
@@ -333,6 +334,7 @@ int marl_set_option(marl_ctx* ctx, const char* name, int64_t value)
     else if (n == "radau_solver") ctx->radau_solver = value ? 1 : 0;
     else if (n == "radau_cr") ctx->radau_cr = (value < 0) ? -1 : std::min<int64_t>(value, radau::CR_MAX_LEVELS);
     else if (n == "radau_cr_min_n") ctx->radau_cr_min_n = std::max<int64_t>(value, 4);
+    else if (n == "radau_cr_tail") ctx->radau_cr_tail = value ? 1 : 0;
     else if (n == "radau_fused_solve") ctx->radau_fused_solve = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "radau_sweep_wg") ctx->radau_sweep_wg = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "implicit_zero_copy") ctx->implicit_zero_copy = value ? 1 : 0;
@@ -1610,16 +1612,45 @@ int radau_solve(marl_ctx* ctx, RadauWork& w, bool both)
         return 0;
     }
     if (!w.cr_k) return pcr_solve_launch(ctx, w, N, both, w.rhs_r, w.rhs_c);
-    // right-hand sides down the reduction levels, the compact system by PCR, solutions back up (in place from level to level)
+    // right-hand sides down the reduction levels, the compact system by PCR, solutions back up (in place from level to level); from the
+    // first level of at most CR_TAIL_ROWS rows on, all remaining levels in one launch each way (option radau_cr_tail = 0: level by level)
     const unsigned gy = both ? 2 : 1;
-    for (int l = 0; l < w.cr_k; l++) {
+    int tail0 = w.cr_k;
+    if (ctx->radau_cr_tail) {
+        while (tail0 > 0 && w.cr_n[tail0 - 1] <= radau::CR_TAIL_ROWS && w.cr_k - (tail0 - 1) <= radau::CR_TAIL_MAX_LEVELS) tail0--;
+    }
+    const int tailJ = w.cr_k - tail0;
+    radau::CrTail tail{};
+    tail.l0 = tail0;
+    for (int j = 0; j <= tailJ; j++) { tail.n[j] = w.cr_n[tail0 + j]; tail.off[j] = w.cr_off[tail0 + j]; }
+    for (int l = 0; l < tail0; l++) {
         const radau::CrShape sh{w.cr_n[l], w.cr_off[l], w.cr_n[l + 1], w.cr_off[l + 1]};
         hipLaunchKernelGGL(radau::cr_rhs_kernel, dim3(blocks256(NF * sh.n_next), gy), dim3(256), 0, ctx->stream, w.Cr, w.Cc, sh, l, w.rhs_r, w.rhs_c);
         LAUNCH_OK(ctx);
     }
+#define MARL_TAIL(KERNEL, BLOCKS)                                                                                                               \
+    switch (tailJ) {                                                                                                                            \
+        case 1: hipLaunchKernelGGL(radau::KERNEL<1>, dim3(BLOCKS, gy), dim3(radau::CR_TAIL_THREADS), 0, ctx->stream, w.Cr, w.Cc, tail, w.rhs_r, w.rhs_c); break; \
+        case 2: hipLaunchKernelGGL(radau::KERNEL<2>, dim3(BLOCKS, gy), dim3(radau::CR_TAIL_THREADS), 0, ctx->stream, w.Cr, w.Cc, tail, w.rhs_r, w.rhs_c); break; \
+        case 3: hipLaunchKernelGGL(radau::KERNEL<3>, dim3(BLOCKS, gy), dim3(radau::CR_TAIL_THREADS), 0, ctx->stream, w.Cr, w.Cc, tail, w.rhs_r, w.rhs_c); break; \
+        case 4: hipLaunchKernelGGL(radau::KERNEL<4>, dim3(BLOCKS, gy), dim3(radau::CR_TAIL_THREADS), 0, ctx->stream, w.Cr, w.Cc, tail, w.rhs_r, w.rhs_c); break; \
+        case 5: hipLaunchKernelGGL(radau::KERNEL<5>, dim3(BLOCKS, gy), dim3(radau::CR_TAIL_THREADS), 0, ctx->stream, w.Cr, w.Cc, tail, w.rhs_r, w.rhs_c); break; \
+        default: hipLaunchKernelGGL(radau::KERNEL<6>, dim3(BLOCKS, gy), dim3(radau::CR_TAIL_THREADS), 0, ctx->stream, w.Cr, w.Cc, tail, w.rhs_r, w.rhs_c); break; \
+    }                                                                                                                                           \
+    LAUNCH_OK(ctx);
+    if (tailJ > 0) {
+        const unsigned nb = (unsigned)((tail.n[tailJ] + radau::CR_TAIL_TOP - 1) / radau::CR_TAIL_TOP);
+        MARL_TAIL(cr_rhs_tail_kernel, nb)
+    }
     const int64_t offk = w.cr_off[w.cr_k];
     if (int rc = pcr_solve_launch(ctx, w, w.cr_n[w.cr_k], both, w.Cr.b + offk * NF, w.Cc.b + offk * NF)) return rc;
-    for (int l = w.cr_k - 1; l >= 0; l--) {
+    if (tailJ > 0) {
+        const int64_t rows = (int64_t)radau::CR_TAIL_TOP << tailJ;
+        const unsigned nb = (unsigned)((tail.n[0] + rows - 1) / rows);
+        MARL_TAIL(cr_back_tail_kernel, nb)
+    }
+#undef MARL_TAIL
+    for (int l = tail0 - 1; l >= 0; l--) {
         const radau::CrShape sh{w.cr_n[l], w.cr_off[l], w.cr_n[l + 1], w.cr_off[l + 1]};
         hipLaunchKernelGGL(radau::cr_back_kernel, dim3((unsigned)((sh.n_cur + radau::CR_ROWS_PER_BLOCK - 1) / radau::CR_ROWS_PER_BLOCK), gy),
                            dim3(radau::CR_ROWS_PER_BLOCK * NF), 0, ctx->stream, w.Cr, w.Cc, sh, l, w.rhs_r, w.rhs_c);

@@ -238,5 +238,177 @@ __global__ void __launch_bounds__(CR_ROWS_PER_BLOCK* NF) cr_back_kernel(CrSystem
     }
 }
 
+// ---- the launch-bound tail of a solve: several levels per launch -------------------------------------------------------------
+// From the level where a launch no longer fills the machine (<= CR_TAIL_ROWS rows) every level kernel above costs its ~5.5 us of
+// dispatch and drain, whatever it computes (N = 64 000: six of nine levels, 2 x 34 us of a 150 us solve).  The tail kernels walk J
+// levels in one launch: a workgroup owns CR_TAIL_TOP rows of the deepest level and everything below them, keeps the vectors of the
+// levels in between in LDS, and recomputes the few rows at its tile's edges that its neighbours compute as well (2^j - 1 rows at the
+// j-th level from the top), so no workgroup waits for another.  Same recurrences in the same order as cr_rhs_row / cr_back_value:
+// bit-identical to the level-by-level kernels.
+constexpr int CR_TAIL_MAX_LEVELS = 6;
+constexpr int CR_TAIL_TOP = 4;                                                                   // rows of the deepest level per workgroup
+constexpr int64_t CR_TAIL_ROWS = 8192;                                                            // the tail starts at the first level this small
+constexpr int CR_TAIL_TILE = (CR_TAIL_TOP + 2) << CR_TAIL_MAX_LEVELS;                             // rows of the tail's first level a workgroup may touch
+constexpr int CR_TAIL_THREADS = 1024;
+struct CrTail {
+    int l0;                                      // levels l0 .. l0 + J - 1 are reduced / back-substituted here (J: template parameter)
+    int64_t n[CR_TAIL_MAX_LEVELS + 1], off[CR_TAIL_MAX_LEVELS + 1];   // rows / first row of level l0 + j
+};
+
+// forward: b_{l0} -> b_{l0+1} ... b_{l0+J} (all written: the way back needs the right-hand sides of the rows each level eliminates)
+template <class T, int J>
+__device__ void cr_rhs_tail(const CrSystem<T>& C, const CrTail& t, const T* __restrict__ b0, T* lds)
+{
+    const int64_t nJ = t.n[J];
+    const int64_t Q0 = (int64_t)blockIdx.x * CR_TAIL_TOP;
+    const int64_t Q1 = (Q0 + CR_TAIL_TOP < nJ) ? Q0 + CR_TAIL_TOP : nJ;
+    const bool last = Q1 == nJ;
+    static_assert(J >= 1 && J <= CR_TAIL_MAX_LEVELS, "levels per tail launch");
+    int64_t lo[J + 1], hi[J + 1];   // rows of level l0 + j this workgroup needs (inclusive)
+    lo[J] = Q0; hi[J] = Q1 - 1;
+#pragma unroll
+    for (int j = J - 1; j >= 0; j--) {
+        {
+            lo[j] = 2 * lo[j + 1];
+            const int64_t h = 2 * hi[j + 1] + 2;
+            hi[j] = (last || h > t.n[j] - 1) ? t.n[j] - 1 : h;   // the last workgroup also takes the rows beyond 2^(J-j) n_J
+        }
+    }
+    T* cur = lds;
+    T* nxt = lds + CR_TAIL_TILE * NF;
+    {
+        const T* src = (t.l0 == 0 ? b0 : C.b + t.off[0] * NF) + lo[0] * NF;
+        const int cnt = (int)(hi[0] - lo[0] + 1) * NF;
+        for (int k = threadIdx.x; k < cnt; k += CR_TAIL_THREADS) cur[k] = src[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const int64_t own_lo = Q0 << (J - j - 1), own_hi = last ? t.n[j + 1] : (Q1 << (J - j - 1));
+        const int cnt = (int)(hi[j + 1] - lo[j + 1] + 1) * NF;
+        T* out = C.b + t.off[j + 1] * NF;
+        for (int k = threadIdx.x; k < cnt; k += CR_TAIL_THREADS) {
+            const int64_t q = lo[j + 1] + k / NF;
+            const int r = k % NF;
+            const int64_t p = 2 * q + 1;
+            const T* bl = cur + (p - lo[j]) * NF;          // row p of level j in the tile
+            T acc = bl[r];
+            const T* al = C.alpha + (t.off[j] + p) * 25 + r * NF;
+#pragma unroll
+            for (int kk = 0; kk < NF; kk++) acc = madd(acc, al[kk], bl[kk - NF]);
+            if (p + 1 < t.n[j]) {
+                const T* ga = C.gamma + (t.off[j] + p) * 25 + r * NF;
+#pragma unroll
+                for (int kk = 0; kk < NF; kk++) acc = madd(acc, ga[kk], bl[kk + NF]);
+            }
+            nxt[k] = acc;
+            if (q >= own_lo && q < own_hi) out[q * NF + r] = acc;
+        }
+        __syncthreads();
+        T* sw = cur; cur = nxt; nxt = sw;
+    }
+}
+
+template <int J>
+__global__ void __launch_bounds__(CR_TAIL_THREADS) cr_rhs_tail_kernel(CrSystem<double> Cr, CrSystem<cplx> Cc, CrTail t, const double* __restrict__ b0_r,
+                                                                       const cplx* __restrict__ b0_c)
+{
+    __shared__ cplx lds[(CR_TAIL_TILE + CR_TAIL_TILE / 2 + 2) * NF];   // (the real system uses half of the bytes)
+    if (blockIdx.y == 0) cr_rhs_tail<double, J>(Cr, t, b0_r, reinterpret_cast<double*>(lds));
+    else cr_rhs_tail<cplx, J>(Cc, t, b0_c, lds);
+}
+
+// backward: x_{l0+J} (in C.b, left there by the PCR solve) -> x_{l0}, written over b_{l0}; the levels in between live in LDS only
+template <class T, int J>
+__device__ void cr_back_tail(const CrSystem<T>& C, const CrTail& t, T* b0, T* lds)
+{
+    const int64_t tile = (int64_t)CR_TAIL_TOP << J;
+    const int64_t P0 = (int64_t)blockIdx.x * tile;
+    const int64_t P1 = (P0 + tile < t.n[0]) ? P0 + tile : t.n[0];
+    int64_t lo[J + 1], hi[J + 1];
+    lo[0] = P0; hi[0] = P1 - 1;
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        {
+            const int64_t l = (lo[j] >> 1) - 1, h = hi[j] >> 1;       // even p needs x_{p/2 - 1}, x_{p/2}; odd p x_{(p-1)/2}
+            lo[j + 1] = l < 0 ? 0 : l;
+            hi[j + 1] = h > t.n[j + 1] - 1 ? t.n[j + 1] - 1 : h;
+        }
+    }
+    T* cur = lds;                               // x of level j + 1
+    T* nxt = lds + CR_TAIL_TILE * NF;           // x of level j
+    {
+        const T* src = C.b + (t.off[J] + lo[J]) * NF;
+        const int cnt = (int)(hi[J] - lo[J] + 1) * NF;
+        for (int k = threadIdx.x; k < cnt; k += CR_TAIL_THREADS) cur[k] = src[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = J - 1; j >= 0; j--) {
+        const int cnt = (int)(hi[j] - lo[j] + 1) * NF;
+        T* bj = (t.l0 + j == 0) ? b0 : C.b + t.off[j] * NF;
+        // j == 0 writes over the right-hand sides it reads (a row's five threads read each other's): every value of a pass is formed
+        // before any is stored.  cnt <= 5 tile rows = at most 5 passes of the 256 threads.
+        T keep[((CR_TAIL_TOP << J) * NF + CR_TAIL_THREADS - 1) / CR_TAIL_THREADS];
+        int pass = 0;
+        for (int k0 = 0; k0 < cnt; k0 += CR_TAIL_THREADS, pass++) {
+            const int k = k0 + threadIdx.x;
+            if (k >= cnt) continue;
+            const int64_t p = lo[j] + k / NF;
+            const int r = k % NF;
+            const int64_t q = p >> 1;
+            T acc;
+            if (p & 1) acc = cur[(q - lo[j + 1]) * NF + r];
+            else {
+                const T* bp = bj + p * NF;
+                const T* di = C.Dinv + (t.off[j] + p) * 25 + r * NF;
+                acc = mul1(di[0], bp[0]);
+#pragma unroll
+                for (int kk = 1; kk < NF; kk++) acc = madd(acc, di[kk], bp[kk]);
+                if (q >= 1) {
+                    const T* pr = C.P + (t.off[j] + p) * 25 + r * NF;
+                    const T* xm = cur + (q - 1 - lo[j + 1]) * NF;
+#pragma unroll
+                    for (int kk = 0; kk < NF; kk++) acc = madd(acc, pr[kk], xm[kk]);
+                }
+                if (q < t.n[j + 1]) {
+                    const T* qr = C.Q + (t.off[j] + p) * 25 + r * NF;
+                    const T* xp = cur + (q - lo[j + 1]) * NF;
+#pragma unroll
+                    for (int kk = 0; kk < NF; kk++) acc = madd(acc, qr[kk], xp[kk]);
+                }
+            }
+            if (j > 0) nxt[k] = acc;
+            else {
+#pragma unroll
+                for (int u = 0; u < (int)(sizeof(keep) / sizeof(keep[0])); u++)
+                    if (u == pass) keep[u] = acc;
+            }
+        }
+        __syncthreads();
+        if (j == 0) {
+            pass = 0;
+            for (int k0 = 0; k0 < cnt; k0 += CR_TAIL_THREADS, pass++) {
+                const int k = k0 + threadIdx.x;
+                if (k >= cnt) continue;
+                T v = keep[0];
+#pragma unroll
+                for (int u = 1; u < (int)(sizeof(keep) / sizeof(keep[0])); u++)
+                    if (u == pass) v = keep[u];
+                bj[lo[0] * NF + k] = v;
+            }
+        }
+        T* sw = cur; cur = nxt; nxt = sw;
+    }
+}
+
+template <int J>
+__global__ void __launch_bounds__(CR_TAIL_THREADS) cr_back_tail_kernel(CrSystem<double> Cr, CrSystem<cplx> Cc, CrTail t, double* b0_r, cplx* b0_c)
+{
+    __shared__ cplx lds[(CR_TAIL_TILE + CR_TAIL_TILE / 2 + 2) * NF];
+    if (blockIdx.y == 0) cr_back_tail<double, J>(Cr, t, b0_r, reinterpret_cast<double*>(lds));
+    else cr_back_tail<cplx, J>(Cc, t, b0_c, lds);
+}
+
 }  // namespace radau
 }  // namespace marl
