@@ -19,6 +19,7 @@
 #include "marl_radau_batch.h"
 #include "marl_radau_wg.h"
 #include "marl_bdf.h"
+#include "marl_bdf_wg.h"
 
 using namespace marl;
 
@@ -87,6 +88,7 @@ struct marl_ctx {
     int64_t radau_cr = -1;      // single runs: levels of cyclic reduction in front of PCR; -1 = automatic (grids of >= radau_cr_min_n cells: down to a
                                 // compact system that fits the one-launch solve with one unknown per thread), 0 = none
     int64_t radau_cr_min_n = 2048;
+    int64_t bdf_solve_wg = 1;   // small grids: solve_bdf_system as one launch of one workgroup (marl_bdf_wg.h); 0: one launch + wait per Newton iteration
     int64_t radau_cr_tail = 1;  // the launch-bound levels of a cyclic-reduction solve in one launch each way (0: one launch per level)
     int64_t radau_sweep_wg = 1; // sweeps of small grids: 1 hybrid (workgroup per instance for the sequential work, launch kernels for Jacobians / factorisations), 2 all in the workgroup, 0 launch per action
     std::string err;
@@ -335,6 +337,7 @@ int marl_set_option(marl_ctx* ctx, const char* name, int64_t value)
     else if (n == "radau_cr") ctx->radau_cr = (value < 0) ? -1 : std::min<int64_t>(value, radau::CR_MAX_LEVELS);
     else if (n == "radau_cr_min_n") ctx->radau_cr_min_n = std::max<int64_t>(value, 4);
     else if (n == "radau_cr_tail") ctx->radau_cr_tail = value ? 1 : 0;
+    else if (n == "bdf_solve_wg") ctx->bdf_solve_wg = value ? 1 : 0;
     else if (n == "radau_fused_solve") ctx->radau_fused_solve = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "radau_sweep_wg") ctx->radau_sweep_wg = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "implicit_zero_copy") ctx->implicit_zero_copy = value ? 1 : 0;
@@ -2139,7 +2142,9 @@ int bdf_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_step
     LAUNCH_OK(ctx);
     int order = 1, n_equal_steps = 0;
     bool have_lu = false;
-    double g[7], g_new[7];
+    double g[7], g_new[7], g_spec[7];
+    bool have_g_spec = false;   // g_spec: the monitors of the state the last converged solve left in w.ynew (solve_wg)
+    const bool solve_wg = ctx->bdf_solve_wg && ctx->zc_on && !w.cr_k && n <= radau::PCR_FUSED_MAX && ctx->radau_fused_solve;
     if (int rc = radau_monitors(ctx, w.y, g)) return rc;
     int64_t eval_i = 0, attempts = 0;
     int status = 1;
@@ -2172,8 +2177,10 @@ int bdf_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_step
             }
             h = t_new - t;
             h_abs = std::fabs(h);
-            hipLaunchKernelGGL(bdf::predict_kernel, gn, b256, 0, ctx->stream, D, n, order, gamma, alpha[order], rtol, atol, ypred, w.scale, psi, w.ynew, d);
-            LAUNCH_OK(ctx);
+            if (!solve_wg) {
+                hipLaunchKernelGGL(bdf::predict_kernel, gn, b256, 0, ctx->stream, D, n, order, gamma, alpha[order], rtol, atol, ypred, w.scale, psi, w.ynew, d);
+                LAUNCH_OK(ctx);
+            }
             bool converged = false;
             bool fused_err = false;   // the converged iteration's launch also left the local error sum (small systems, zero-copy words)
             const double c = h / alpha[order];
@@ -2184,14 +2191,37 @@ int bdf_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_step
                     st->nlu++;
                     have_lu = true;
                 }
-                if (!first_pass) {
+                if (!first_pass && !solve_wg) {
                     hipLaunchKernelGGL(bdf::newton_restart_kernel, gn, b256, 0, ctx->stream, ypred, n, w.ynew, d);
                     LAUNCH_OK(ctx);
                 }
+                const int wg_mode = first_pass ? 0 : 1;
                 first_pass = false;
                 // ---- solve_bdf_system (bdf.py:36-68) ----
                 double dy_norm_old = -1;
                 int k;
+                if (solve_wg) {   // predictor / restart, every Newton iteration with its tests, error sum and monitors: one launch, one wait
+                    if (ctx->var_dphi)
+                        hipLaunchKernelGGL(bdf::solve_wg_kernel<true>, dim3(1), dim3(radau::WG_THREADS), 0, ctx->stream, wg_mode, D, order, gamma, alpha[order], ypred,
+                                           psi, w.scale, w.ynew, d, f, N, c, w.nlevels, w.Sr, ctx->dconsts, newton_tol, error_const[order], rtol, atol, ctx->zc_d);
+                    else
+                        hipLaunchKernelGGL(bdf::solve_wg_kernel<false>, dim3(1), dim3(radau::WG_THREADS), 0, ctx->stream, wg_mode, D, order, gamma, alpha[order], ypred,
+                                           psi, w.scale, w.ynew, d, f, N, c, w.nlevels, w.Sr, ctx->dconsts, newton_tol, error_const[order], rtol, atol, ctx->zc_d);
+                    LAUNCH_OK(ctx);
+                    double ss;
+                    int nonfinite;
+                    if (int rc = radau_read(ctx, w, &ss, &nonfinite)) return rc;
+                    const volatile double* zw = const_cast<const volatile double*>(ctx->zc_h);
+                    const int iters = (int)zw[bdf::SW_ITERS];
+                    st->nfev += iters;
+                    converged = zw[bdf::SW_CONVERGED] != 0;
+                    fused_err = converged;
+                    if (converged) {
+                        for (int e = 0; e < 7; e++) g_spec[e] = zw[bdf::SW_G + e];
+                        have_g_spec = true;
+                    }
+                    k = iters - 1;
+                } else
                 for (k = 0; k < NEWTON_MAXITER; k++) {
                     if (int rc = launch_rhs(ctx, w.ynew, f, LAYOUT_FIELD_MAJOR)) return rc;
                     st->nfev++;
@@ -2310,7 +2340,10 @@ int bdf_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_step
 
         // events and t_eval on the dense output built AFTER the order / step-size update (bdf.py:452-454)
         const BdfDense dense = {t, S_h_abs, order, D};
-        if (int rc = radau_monitors(ctx, w.y, g_new)) return rc;
+        if (solve_wg && have_g_spec) {   // y = the state of the last converged solve: its monitors came with the solve
+            for (int e = 0; e < 7; e++) g_new[e] = g_spec[e];
+        } else if (int rc = radau_monitors(ctx, w.y, g_new)) return rc;
+        have_g_spec = false;
         for (int e = 0; e < 7; e++) {
             const bool up = g[e] <= 0 && g_new[e] >= 0, down = g[e] >= 0 && g_new[e] <= 0;
             if (up || down) {
