@@ -58,6 +58,11 @@ int marl_synchronize(marl_ctx* ctx);
  *   memory that the kernels write and the host polls; 0: a copy and a stream synchronisation per read - bit-identical),
  *   radau_fused_solve (1, the default: systems of up to 2048 unknowns run every cyclic-reduction level of a solve in one
  *   launch; 0: one launch per level - bit-identical),
+ *   radau_cr (single Radau / BDF runs: levels of block cyclic reduction in front of the parallel cyclic reduction; -1, the default:
+ *   automatic for grids of radau_cr_min_n (2048) cells or more, down to a compact system of at most 204 rows; 0: none; k > 0: k levels),
+ *   radau_cr_tail (1, the default: the launch-bound levels of such a solve in one launch each way; 0: one launch per level -
+ *   bit-identical), bdf_solve_wg (1, the default: on grids of up to 409 cells marl_integrate_bdf runs solve_bdf_system as one launch of
+ *   one workgroup; 0: one RHS launch, one linear-algebra launch and one wait per Newton iteration - bit-identical),
  *   rk4_stream (fixed-step RK4 of one grid as ONE dataflow launch over (level, tile) work items instead of one launch per
  *   fused level: 0 never, 1 - the default - for grids of 196 608 cells or more, 2 always; results are bit-identical),
  *   rk4_stream_test_raise (test hook: the next streamed run starts with its give-up flag raised - marl_synchronize must

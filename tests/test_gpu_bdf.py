@@ -140,3 +140,21 @@ def test_bdf_fused_newton_launch_is_bit_identical():
     a, b = out
     assert (a.status, a.nfev, a.njev, a.nlu, a.n_accepted) == (b.status, b.nfev, b.njev, b.nlu, b.n_accepted)
     assert np.array_equal(a.y_final, b.y_final)
+
+
+@pytest.mark.parametrize("name", ["A", "matlab", "A_N64_tight"])
+def test_bdf_workgroup_solve_is_bit_identical_to_the_host_driven_newton_loop(name):
+    """Small grids run solve_bdf_system (bdf.py:36-68) as ONE launch of one workgroup - predictor, every Newton iteration with its
+    convergence tests evaluated on the device, the converged state's error sum and monitors (bdf::solve_wg_kernel; option bdf_solve_wg,
+    default on) - instead of an RHS launch, a linear-algebra launch and a wait per iteration with the tests on the host.  Same vector
+    arithmetic, same scalar tests: statistics, final state and event roots must be identical, not close."""
+    g, p, eq = _model(name)
+    out = []
+    for wg in (0, 1):
+        eq.set_option("bdf_solve_wg", wg)
+        out.append(eq.integrate_bdf(g["y0"], tuple(g["t_span"]), float(g["first_step"]), float(g["rtol"]), float(g["atol"])))
+    eq.close()
+    a, b = out
+    assert (a.status, a.nfev, a.njev, a.nlu, a.n_accepted, a.n_rejected) == (b.status, b.nfev, b.njev, b.nlu, b.n_accepted, b.n_rejected)
+    assert np.array_equal(a.y_final, b.y_final)
+    assert all(np.array_equal(x, y) for x, y in zip(a.t_events, b.t_events))

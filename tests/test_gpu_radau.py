@@ -193,6 +193,26 @@ def test_cyclic_reduction_front_end_against_pcr_and_the_oracle_at_4000_cells(ora
     assert np.max(np.abs(b.y_final - y)) < 1e-3 and np.max(np.abs(a.y_final - y)) < 1e-3      # observed 2.2e-4, 4.6e-5 (rtol = atol = 1e-3)
 
 
+@pytest.mark.parametrize("N", [2048, 5003])
+def test_cyclic_reduction_tail_launches_are_bit_identical_to_level_by_level(N):
+    """From the first level of at most 8192 rows on, a cyclic-reduction solve walks all remaining levels in one launch each way
+    (cr_rhs_tail_kernel / cr_back_tail_kernel: tiles with recomputed edges, option radau_cr_tail, default on) instead of one launch per
+    level - the same recurrences in the same order.  N = 5003: odd row counts on the way down (5003, 2501, 1250, 625, 312, 156)."""
+    from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
+    p = scenario("A", N)
+    y0 = np.concatenate([np.full(N, p[k]) for k in ("CAIni", "CCIni", "cCaIni", "cCO3Ini", "PhiIni")])
+    eq = LMAHeureuxPorosityDiff.from_scenario(p, device=0)
+    out = []
+    for tail in (0, 1):
+        eq.set_option("radau_cr_tail", tail)
+        out.append(eq.integrate_radau(y0, (0.0, 0.2), 1e-6, 1e-3, 1e-3))
+    eq.close()
+    a, b = out
+    assert a.status == b.status == 0
+    assert (a.nfev, a.njev, a.nlu, a.n_accepted) == (b.nfev, b.njev, b.nlu, b.n_accepted)
+    assert np.array_equal(a.y_final, b.y_final)
+
+
 @pytest.mark.parametrize("name", ["A", "matlab"])
 def test_radau_fused_solve_is_bit_identical_to_per_level_solve(oracle, name):
     """Small systems (5 N <= 2048) run all levels of a PCR solve in one launch (pcr_solve_fused_kernel: right-hand side in LDS, a
