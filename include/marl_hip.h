@@ -58,6 +58,9 @@ int marl_synchronize(marl_ctx* ctx);
  *   memory that the kernels write and the host polls; 0: a copy and a stream synchronisation per read - bit-identical),
  *   radau_fused_solve (1, the default: systems of up to 2048 unknowns run every cyclic-reduction level of a solve in one
  *   launch; 0: one launch per level - bit-identical),
+ *   radau_sweep_wg (Radau sweeps of grids of up to 409 cells: 3, the default: a persistent workgroup per instance runs the instance's
+ *   sequential work and its Jacobians, launch kernels over work lists do the factorisations; 1: Jacobians by launch kernels too -
+ *   bit-identical; 2: everything in the workgroup; 0: one launch cycle per action),
  *   radau_cr (single Radau / BDF runs: levels of block cyclic reduction in front of the parallel cyclic reduction; -1, the default:
  *   automatic for grids of radau_cr_min_n (2048) cells or more, down to a compact system of at most 204 rows; 0: none; k > 0: k levels),
  *   radau_cr_tail (1, the default: the launch-bound levels of such a solve in one launch each way; 0: one launch per level -

@@ -90,7 +90,7 @@ struct marl_ctx {
     int64_t radau_cr_min_n = 2048;
     int64_t bdf_solve_wg = 1;   // small grids: solve_bdf_system as one launch of one workgroup (marl_bdf_wg.h); 0: one launch + wait per Newton iteration
     int64_t radau_cr_tail = 1;  // the launch-bound levels of a cyclic-reduction solve in one launch each way (0: one launch per level)
-    int64_t radau_sweep_wg = 1; // sweeps of small grids: 1 hybrid (workgroup per instance for the sequential work, launch kernels for Jacobians / factorisations), 2 all in the workgroup, 0 launch per action
+    int64_t radau_sweep_wg = 3; // sweeps of small grids: 3 hybrid (workgroup per instance for the sequential work and Jacobians, launch kernels for factorisations), 1 hybrid with launch kernels for Jacobians too, 2 all in the workgroup, 0 launch per action
     std::string err;
 };
 
@@ -339,7 +339,7 @@ int marl_set_option(marl_ctx* ctx, const char* name, int64_t value)
     else if (n == "radau_cr_tail") ctx->radau_cr_tail = value ? 1 : 0;
     else if (n == "bdf_solve_wg") ctx->bdf_solve_wg = value ? 1 : 0;
     else if (n == "radau_fused_solve") ctx->radau_fused_solve = value < 0 ? 0 : (value > 2 ? 2 : value);
-    else if (n == "radau_sweep_wg") ctx->radau_sweep_wg = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (n == "radau_sweep_wg") ctx->radau_sweep_wg = value < 0 ? 0 : (value > 3 ? 3 : value);
     else if (n == "implicit_zero_copy") ctx->implicit_zero_copy = value ? 1 : 0;
     else if (n == "rk4_stream") ctx->rk4_stream = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "rk4_stream_test_raise") ctx->sq_test_raise = value != 0;
@@ -2515,10 +2515,12 @@ extern "C" int marl_sweep_radau_events_dev(marl_ctx* ctx, double* y_dev, double 
         if (e_ != hipSuccess) { cleanup(); return fail(ctx, -100 - (int)e_, "kernel launch failed: %s", hipGetErrorString(e_)); } \
     } while (0)
     // Sweeps of small grids (5 N <= PCR_FUSED_MAX: the reference's N = 200), option radau_sweep_wg:
-    //   1 (default)  HYBRID: one persistent workgroup per instance runs everything of the instance that is sequential and small (step
+    //   1            HYBRID: one persistent workgroup per instance runs everything of the instance that is sequential and small (step
     //                logic, Newton iterations, error estimates, accepted steps, event roots - marl_radau_wg.h) and hands it back for
     //                Jacobians and factorisations, which the launch kernels do over work lists on the whole chip: one host cycle per
     //                Jacobian / factorisation instead of one per action;
+    //   3 (default)  HYBRID with the finite-difference Jacobian in the workgroup too (60 us there against a host cycle of ~100 us): only
+    //                factorisations come back to the host cycle - bit-identical to 1;
     //   2            the workgroup does those as well (no host in the loop; measured slower: cyclic reduction on ONE compute unit);
     //   0            the launch-per-action cycle (larger grids always take it).
     const int wg_mode = (n <= PCR_FUSED_MAX) ? (int)ctx->radau_sweep_wg : 0;
@@ -2554,12 +2556,13 @@ extern "C" int marl_sweep_radau_events_dev(marl_ctx* ctx, double* y_dev, double 
         RB_OK();
     }
     int64_t wg_nrun = -1;
-    const bool hybrid = wg_mode == 1 || (wg_mode == 2 && locate);
+    const bool hybrid = wg_mode == 1 || wg_mode == 3 || (wg_mode == 2 && locate);
+    const int hybrid_kind = wg_mode == 3 ? 2 : 1;   // 2: Jacobians stay in the workgroup, only factorisations come back to the host cycle
     for (int64_t cycle = 0; !use_wg; cycle++) {
         // the controllers advance every instance to its next piece of work and sort the instances into work lists; the host
         // reads the list lengths (one small copy + synchronisation per cycle) and launches each kind of work over its list only
         if (!zc_words || cycle == 0) (void)hipMemsetAsync(dcounts, 0, sizeof(int32_t) * L_COUNT, ctx->stream);   // (publish_counts_kernel zeroes them afterwards)
-        if (hybrid) launch_wg(1, wg_nrun);   // every running instance up to its next Jacobian / factorisation (or its end)
+        if (hybrid) launch_wg(hybrid_kind, wg_nrun);   // every running instance up to its next Jacobian / factorisation (or its end)
         else hipLaunchKernelGGL(radau_control_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, ctx->stream, dctl, drec, B, n, dcounts, dlists, drec_dense, dtev);
         RB_OK();
         if (zc_words) {   // the list lengths through polled host memory

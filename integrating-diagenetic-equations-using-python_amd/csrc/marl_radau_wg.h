@@ -184,7 +184,8 @@ __global__ void __launch_bounds__(WG_THREADS) radau_wg_kernel(RadauCtl* __restri
             WG_TICK(0);
             const int32_t action = sc.action;
             if (sc.pc == PC_DONE && action == 0) break;
-            if (hybrid && (action & (A_JAC | A_LU))) {   // back to the host cycle: the launch kernels do this over the work lists
+            // back to the host cycle: the launch kernels do this over the work lists (hybrid == 2: factorisations only - the Jacobian stays here)
+            if (hybrid && ((action & A_LU) || (hybrid == 1 && (action & A_JAC)))) {
                 if (tid == 0) {
                     atomicAdd(&counts[L_RUNNING], 1);
                     const int which = (action & A_JAC) ? L_JAC : L_LU;

@@ -344,9 +344,10 @@ def test_radau_sweep_locates_event_roots_like_the_single_run(torch_cuda_radau):
 
 
 def test_radau_sweep_workgroup_paths_against_the_launch_path(torch_cuda_radau):
-    """Sweeps of small grids (option radau_sweep_wg): 1 = HYBRID, the default - one persistent workgroup per instance runs the sequential
+    """Sweeps of small grids (option radau_sweep_wg): 1 = HYBRID - one persistent workgroup per instance runs the sequential
     work of the instance (step logic, Newton iterations, error estimates, accepted steps, event roots; marl_radau_wg.h) and hands it back to
-    the host cycle for Jacobians and factorisations (launch kernels over work lists); 2 = the workgroup does those too; 0 = one launch
+    the host cycle for Jacobians and factorisations (launch kernels over work lists); 3 = the same with the Jacobian in the workgroup too
+    (the default: only factorisations come back; must be bit-identical to 1); 2 = the workgroup does everything; 0 = one launch
     cycle per action (round 2).  Same step-logic function everywhere.  HYBRID must reproduce the launch path's statistics EXACTLY and its
     states to 1e-12 (same kernels for the factorisations, restated bodies with the same reduction trees for the rest); mode 2 inlines the
     factorisation into the big kernel, where the compiler contracts its complex multiply-adds differently: it agrees like two correct
@@ -361,7 +362,7 @@ def test_radau_sweep_workgroup_paths_against_the_launch_path(torch_cuda_radau):
                 {"Phi0": 0.6, "PhiIni": 0.6, "PhiNR": 0.6}, {"Phi0": 0.65, "PhiIni": 0.5, "PhiNR": 0.5, "k3": 0.05, "k4": 0.05}]
         y0 = np.stack([np.concatenate([np.full(N, (base | d)[k]) for k in ("CAIni", "CCIni", "cCaIni", "cCO3Ini", "PhiIni")]) for d in inst])
         out = {}
-        for wg in (0, 1, 2):
+        for wg in (0, 1, 2, 3):
             eq = LMAHeureuxPorosityDiff.from_scenario(base, device=0, instances=inst)
             eq.use_stream(torch.cuda.current_stream().cuda_stream)
             eq.set_option("radau_sweep_wg", wg)
@@ -375,6 +376,9 @@ def test_radau_sweep_workgroup_paths_against_the_launch_path(torch_cuda_radau):
             assert a.status == h.status == w.status == (2 if budget else 0)
             assert (a.nfev, a.njev, a.nlu, a.n_accepted, a.n_rejected, list(a.n_events)) == (h.nfev, h.njev, h.nlu, h.n_accepted, h.n_rejected, list(h.n_events)), (N, b)
             assert a.t_reached == h.t_reached and np.max(np.abs(out[0][0][b] - out[1][0][b])) <= 1e-12, (N, b, float(np.max(np.abs(out[0][0][b] - out[1][0][b]))))
+            j = out[3][1][b]
+            assert (j.status, j.nfev, j.njev, j.nlu, j.n_accepted, j.n_rejected, list(j.n_events), j.t_reached) == (h.status, h.nfev, h.njev, h.nlu, h.n_accepted, h.n_rejected, list(h.n_events), h.t_reached), (N, b)
+            assert np.array_equal(out[3][0][b], out[1][0][b]), (N, b)
             for x, y in ((a.nfev, w.nfev), (a.njev, w.njev), (a.nlu, w.nlu), (a.n_accepted, w.n_accepted)):
                 assert abs(x - y) <= max(6, 0.1 * x), (N, b, x, y)
             if budget:
