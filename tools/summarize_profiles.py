@@ -19,6 +19,7 @@ import sys
 from collections import defaultdict
 
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+os.makedirs(dst, exist_ok=True)
 N = 1 << 20
 
 
