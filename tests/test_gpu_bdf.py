@@ -158,3 +158,50 @@ def test_bdf_workgroup_solve_is_bit_identical_to_the_host_driven_newton_loop(nam
     assert (a.status, a.nfev, a.njev, a.nlu, a.n_accepted, a.n_rejected) == (b.status, b.nfev, b.njev, b.nlu, b.n_accepted, b.n_rejected)
     assert np.array_equal(a.y_final, b.y_final)
     assert all(np.array_equal(x, y) for x, y in zip(a.t_events, b.t_events))
+
+
+def test_bdf_workgroup_solve_with_the_variable_porosity_diffusion(oracle):
+    """The dPhi_variable instantiation (solve_wg_kernel<VD = true>): bit-identical to the host-driven loop, and the run agrees with the
+    oracle's BDF on the same parameters (statistics equal, states to the solver's tolerance)."""
+    from common import scenario
+    from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
+    N = 200
+    p = scenario("A", N) | {"dPhi_variable": True}
+    y0 = np.concatenate([np.full(N, p[k]) for k in ("CAIni", "CCIni", "cCaIni", "cCO3Ini", "PhiIni")])
+    eq = LMAHeureuxPorosityDiff.from_scenario(p, device=0)
+    out = []
+    for wg in (0, 1):
+        eq.set_option("bdf_solve_wg", wg)
+        out.append(eq.integrate_bdf(y0, (0.0, 0.3), 1e-6, 1e-3, 1e-3))
+    eq.close()
+    a, b = out
+    assert (a.status, a.nfev, a.njev, a.nlu, a.n_accepted, a.n_rejected) == (b.status, b.nfev, b.njev, b.nlu, b.n_accepted, b.n_rejected)
+    assert np.array_equal(a.y_final, b.y_final)
+    y, st, *_ = oracle.bdf(oracle.params_from_dict(p | {"dPhi_variable": 1}), N, y0, 0.0, 0.3, 1e-6, 1e-3, 1e-3)
+    assert st.status == b.status == 0
+    assert abs(b.nfev - st.nfev) <= max(6, 0.03 * st.nfev) and abs(b.n_accepted - st.n_accepted) <= 3
+    assert np.max(np.abs(b.y_final - y)) < 2e-3
+
+
+def test_bdf_cyclic_reduction_front_end_at_2048_cells():
+    """BDF takes the cyclic-reduction front end for its real system I - c J from 2048 cells as Radau does: against plain PCR on a span
+    the method survives (scipy's BDF breaks down on the finer grids of this model, see the breakdown test) - same decisions, states to
+    far below the tolerance; and the tail launches change no bit."""
+    from common import scenario
+    from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
+    N = 2048
+    p = scenario("A", N)
+    y0 = np.concatenate([np.full(N, p[k]) for k in ("CAIni", "CCIni", "cCaIni", "cCO3Ini", "PhiIni")])
+    eq = LMAHeureuxPorosityDiff.from_scenario(p, device=0)
+    out = []
+    for cr, tail in ((0, 1), (-1, 1), (-1, 0)):
+        eq.set_option("radau_cr", cr)
+        eq.set_option("radau_cr_tail", tail)
+        out.append(eq.integrate_bdf(y0, (0.0, 0.02), 1e-6, 1e-3, 1e-3))
+    eq.close()
+    a, b, c = out
+    print([(r.status, r.nfev, r.njev, r.nlu, r.n_accepted) for r in out], float(np.max(np.abs(a.y_final - b.y_final))))
+    assert a.status == b.status == c.status == 0
+    assert (b.nfev, b.njev, b.nlu, b.n_accepted) == (c.nfev, c.njev, c.nlu, c.n_accepted) and np.array_equal(b.y_final, c.y_final)
+    assert abs(a.nfev - b.nfev) <= max(6, 0.03 * a.nfev) and abs(a.n_accepted - b.n_accepted) <= 3
+    assert np.max(np.abs(a.y_final - b.y_final)) < 1e-3
