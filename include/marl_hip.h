@@ -63,6 +63,9 @@ int marl_synchronize(marl_ctx* ctx);
  *   bit-identical; 2: everything in the workgroup; 0: one launch cycle per action),
  *   radau_cr (single Radau / BDF runs: levels of block cyclic reduction in front of the parallel cyclic reduction; -1, the default:
  *   automatic for grids of radau_cr_min_n (2048) cells or more, down to a compact system of at most 204 rows; 0: none; k > 0: k levels),
+ *   radau_cr_small / radau_cr_small_min_n (grids solved in one workgroup, up to 409 cells: 3 levels of cyclic reduction in front of PCR
+ *   inside the one-launch solves, by default from 205 cells; min_n = 32 turns it on for the reference's N = 200 - faster sweeps, but no
+ *   longer decision-by-decision equal to scipy in every pinned case),
  *   radau_cr_tail (1, the default: the launch-bound levels of such a solve in one launch each way; 0: one launch per level -
  *   bit-identical), bdf_solve_wg (1, the default: on grids of up to 409 cells marl_integrate_bdf runs solve_bdf_system as one launch of
  *   one workgroup; 0: one RHS launch, one linear-algebra launch and one wait per Newton iteration - bit-identical),

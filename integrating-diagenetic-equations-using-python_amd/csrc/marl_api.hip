@@ -88,6 +88,8 @@ struct marl_ctx {
     int64_t radau_cr = -1;      // single runs: levels of cyclic reduction in front of PCR; -1 = automatic (grids of >= radau_cr_min_n cells: down to a
                                 // compact system that fits the one-launch solve with one unknown per thread), 0 = none
     int64_t radau_cr_min_n = 2048;
+    int64_t radau_cr_small = 3; // grids solved in one workgroup (up to 409 cells): levels of cyclic reduction in front of PCR (0: none)
+    int64_t radau_cr_small_min_n = 205;   // ... from this many cells on (below: plain PCR, which reproduces scipy's decisions on the reference's N = 200 runs)
     int64_t bdf_solve_wg = 1;   // small grids: solve_bdf_system as one launch of one workgroup (marl_bdf_wg.h); 0: one launch + wait per Newton iteration
     int64_t radau_cr_tail = 1;  // the launch-bound levels of a cyclic-reduction solve in one launch each way (0: one launch per level)
     int64_t radau_sweep_wg = 3; // sweeps of small grids: 3 hybrid (workgroup per instance for the sequential work and Jacobians, launch kernels for factorisations), 1 hybrid with launch kernels for Jacobians too, 2 all in the workgroup, 0 launch per action
@@ -336,6 +338,8 @@ int marl_set_option(marl_ctx* ctx, const char* name, int64_t value)
     else if (n == "radau_solver") ctx->radau_solver = value ? 1 : 0;
     else if (n == "radau_cr") ctx->radau_cr = (value < 0) ? -1 : std::min<int64_t>(value, radau::CR_MAX_LEVELS);
     else if (n == "radau_cr_min_n") ctx->radau_cr_min_n = std::max<int64_t>(value, 4);
+    else if (n == "radau_cr_small") ctx->radau_cr_small = value < 0 ? 0 : std::min<int64_t>(value, radau::CR_WG_MAX_LEVELS);
+    else if (n == "radau_cr_small_min_n") ctx->radau_cr_small_min_n = std::max<int64_t>(value, 32);
     else if (n == "radau_cr_tail") ctx->radau_cr_tail = value ? 1 : 0;
     else if (n == "bdf_solve_wg") ctx->bdf_solve_wg = value ? 1 : 0;
     else if (n == "radau_fused_solve") ctx->radau_fused_solve = value < 0 ? 0 : (value > 2 ? 2 : value);
@@ -1409,6 +1413,7 @@ struct RadauWork {
     int64_t cr_n[radau::CR_MAX_LEVELS + 1] = {}, cr_off[radau::CR_MAX_LEVELS + 2] = {};
     radau::CrSystem<double> Cr{};
     radau::CrSystem<cplx> Cc{};
+    radau::CrPlan plan{};   // the same levels for the one-launch solve kernels (plan.k == 0: they run PCR alone)
 };
 
 // Zero-copy slots: arm = store the sentinel; wait = poll until the kernel has overwritten it (bounded, then fall back to a synchronise).
@@ -1459,14 +1464,31 @@ int radau_alloc(marl_ctx* ctx, RadauWork& w, const int32_t* groups_host, int64_t
     // cyclic-reduction levels in front of PCR (single runs with the PCR solver only)
     w.cr_k = 0;
     w.cr_n[0] = N; w.cr_off[0] = 0;
-    if (instances == 1 && ctx->radau_solver == 0 && ctx->radau_cr != 0 && (ctx->radau_cr > 0 || N >= ctx->radau_cr_min_n)) {
+    // Small grids whose solves run in one workgroup (5 N <= PCR_FUSED_MAX, single runs and sweeps): radau_cr_small levels (default 3) -
+    // the chain of levels in one workgroup is bound by the factor bytes that pass through one compute unit, and cyclic reduction
+    // in front of PCR cuts them 2.4 - 2.8 times (marl_radau.h, crpcr_solve_all).  The all-in-workgroup sweep mode keeps plain PCR.
+    // By default only from radau_cr_small_min_n = 205 cells (two unknowns per thread of the chain): on the reference's N = 200 grid
+    // plain PCR is what takes every decision scipy takes in single runs AND sweeps (with 1 - 3 levels in front, one knife-edge Newton
+    // test or another falls the other way in one of the pinned cases - profiles/r03_lab_radau_wg.log); set radau_cr_small_min_n = 32
+    // for throughput there (4096 scenarios: 1.58 -> 1.17 s).
+    const bool one_wg = n <= radau::PCR_FUSED_MAX && N >= 32 && (instances == 1 || ctx->radau_fused_solve);   // (single runs with radau_fused_solve = 0: the same levels, one launch each)
+    const bool small_cr = one_wg && ctx->radau_cr < 0 && ctx->radau_cr_small > 0 && N >= ctx->radau_cr_small_min_n && !(instances > 1 && ctx->radau_sweep_wg == 2);
+    const bool large_cr = instances == 1 && ctx->radau_cr != 0 && (ctx->radau_cr > 0 || N >= ctx->radau_cr_min_n);
+    if (ctx->radau_solver == 0 && (small_cr || large_cr)) {
+        const int64_t want = small_cr ? ctx->radau_cr_small : ctx->radau_cr;
         int k = 0;
-        while (k < radau::CR_MAX_LEVELS && w.cr_n[k] / 2 >= 2 && (ctx->radau_cr > 0 ? k < ctx->radau_cr : NF * w.cr_n[k] > radau::PCR_FUSED_THREADS)) {
+        while (k < radau::CR_MAX_LEVELS && w.cr_n[k] / 2 >= 2 && (want > 0 ? k < want : NF * w.cr_n[k] > radau::PCR_FUSED_THREADS)) {
             w.cr_n[k + 1] = w.cr_n[k] / 2;
             w.cr_off[k + 1] = w.cr_off[k] + w.cr_n[k];
             k++;
         }
         w.cr_k = k;
+    }
+    // the levels as the one-launch solve kernels take them (k <= CR_WG_MAX_LEVELS; else they are not used)
+    w.plan = radau::CrPlan{};
+    if (w.cr_k > 0 && w.cr_k <= radau::CR_WG_MAX_LEVELS && n <= radau::PCR_FUSED_MAX) {
+        w.plan.k = w.cr_k;
+        for (int l = 0; l <= w.cr_k; l++) { w.plan.n[l] = w.cr_n[l]; w.plan.off[l] = w.cr_off[l]; }
     }
     const int64_t M = w.cr_n[w.cr_k];                                      // rows of the system PCR works on
     const int64_t cr_rows = w.cr_k ? w.cr_off[w.cr_k] + M : 0;             // rows of all levels together (< 2 N)
@@ -1615,6 +1637,12 @@ int radau_solve(marl_ctx* ctx, RadauWork& w, bool both)
         return 0;
     }
     if (!w.cr_k) return pcr_solve_launch(ctx, w, N, both, w.rhs_r, w.rhs_c);
+    if (w.plan.k && ctx->radau_fused_solve) {   // small grids: reduction levels, compact PCR and back-substitution in one launch (crpcr_solve_all)
+        hipLaunchKernelGGL(radau::pcr_solve_fused_kernel, dim3(1, both ? 2 : 1), dim3(radau::PCR_FUSED_THREADS), 0, ctx->stream, N, w.nlevels, 0, w.Sr, w.Sc,
+                           w.rhs_r, w.rhs_r, w.rhs_c, w.rhs_c, ZBatch{0, nullptr, 0, 0, nullptr}, w.plan, w.Cr, w.Cc);
+        LAUNCH_OK(ctx);
+        return 0;
+    }
     // right-hand sides down the reduction levels, the compact system by PCR, solutions back up (in place from level to level); from the
     // first level of at most CR_TAIL_ROWS rows on, all remaining levels in one launch each way (option radau_cr_tail = 0: level by level)
     const unsigned gy = both ? 2 : 1;
@@ -1878,9 +1906,9 @@ int radau_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_st
                 for (k = 0; k < NEWTON_MAXITER; k++) {
                     if (int rc = launch_rhs(ctx, w.YS, w.F, LAYOUT_FIELD_MAJOR, 3)) return rc;
                     st->nfev += 3;
-                    if (w.pcr && !w.cr_k && n <= radau::PCR_FUSED_MAX && ctx->radau_fused_solve >= 2) {   // right-hand sides + both solves + update + norm: one launch
+                    if (w.pcr && (!w.cr_k || w.plan.k) && n <= radau::PCR_FUSED_MAX && ctx->radau_fused_solve >= 2) {   // right-hand sides + both solves + update + norm: one launch
                         hipLaunchKernelGGL(radau::newton_fused_kernel, dim3(1), dim3(radau::PCR_FUSED_THREADS), 0, ctx->stream, w.y, w.F, N, M_real, M_c, w.nlevels, w.Sr,
-                                           w.Sc, w.scale, w.W, w.Z, w.YS, w.rhs_r, w.rhs_c, w.flags, w.out);
+                                           w.Sc, w.scale, w.W, w.Z, w.YS, w.rhs_r, w.rhs_c, w.flags, w.out, w.plan, w.Cr, w.Cc);
                         LAUNCH_OK(ctx);
                     } else {
                     hipLaunchKernelGGL(radau::newton_rhs_kernel, gn, b256, 0, ctx->stream, w.F, w.W, N, M_real, M_c, w.rhs_r, w.rhs_c, w.flags);
@@ -2144,7 +2172,7 @@ int bdf_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_step
     bool have_lu = false;
     double g[7], g_new[7], g_spec[7];
     bool have_g_spec = false;   // g_spec: the monitors of the state the last converged solve left in w.ynew (solve_wg)
-    const bool solve_wg = ctx->bdf_solve_wg && ctx->zc_on && !w.cr_k && n <= radau::PCR_FUSED_MAX && ctx->radau_fused_solve;
+    const bool solve_wg = ctx->bdf_solve_wg && ctx->zc_on && (!w.cr_k || w.plan.k) && n <= radau::PCR_FUSED_MAX && ctx->radau_fused_solve;
     if (int rc = radau_monitors(ctx, w.y, g)) return rc;
     int64_t eval_i = 0, attempts = 0;
     int status = 1;
@@ -2203,10 +2231,10 @@ int bdf_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_step
                 if (solve_wg) {   // predictor / restart, every Newton iteration with its tests, error sum and monitors: one launch, one wait
                     if (ctx->var_dphi)
                         hipLaunchKernelGGL(bdf::solve_wg_kernel<true>, dim3(1), dim3(radau::WG_THREADS), 0, ctx->stream, wg_mode, D, order, gamma, alpha[order], ypred,
-                                           psi, w.scale, w.ynew, d, f, N, c, w.nlevels, w.Sr, ctx->dconsts, newton_tol, error_const[order], rtol, atol, ctx->zc_d);
+                                           psi, w.scale, w.ynew, d, f, N, c, w.nlevels, w.Sr, ctx->dconsts, newton_tol, error_const[order], rtol, atol, ctx->zc_d, w.plan, w.Cr);
                     else
                         hipLaunchKernelGGL(bdf::solve_wg_kernel<false>, dim3(1), dim3(radau::WG_THREADS), 0, ctx->stream, wg_mode, D, order, gamma, alpha[order], ypred,
-                                           psi, w.scale, w.ynew, d, f, N, c, w.nlevels, w.Sr, ctx->dconsts, newton_tol, error_const[order], rtol, atol, ctx->zc_d);
+                                           psi, w.scale, w.ynew, d, f, N, c, w.nlevels, w.Sr, ctx->dconsts, newton_tol, error_const[order], rtol, atol, ctx->zc_d, w.plan, w.Cr);
                     LAUNCH_OK(ctx);
                     double ss;
                     int nonfinite;
@@ -2225,12 +2253,12 @@ int bdf_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_step
                 for (k = 0; k < NEWTON_MAXITER; k++) {
                     if (int rc = launch_rhs(ctx, w.ynew, f, LAYOUT_FIELD_MAJOR)) return rc;
                     st->nfev++;
-                    if (!w.cr_k && n <= radau::PCR_FUSED_MAX && ctx->radau_fused_solve) {   // right-hand side + every level + update + norm in one launch
+                    if ((!w.cr_k || w.plan.k) && n <= radau::PCR_FUSED_MAX && ctx->radau_fused_solve) {   // right-hand side + every level + update + norm in one launch
                         // (with the zero-copy result words: the step's local error norm rides along - bdf.py:398-400 - one launch and
                         //  one wait less per step)
                         fused_err = ctx->zc_on;
                         hipLaunchKernelGGL(bdf::newton_fused_kernel, dim3(1), dim3(radau::PCR_FUSED_THREADS), 0, ctx->stream, f, psi, N, c, w.nlevels, w.Sr, w.scale,
-                                           w.ynew, d, w.flags, w.out, error_const[order], rtol, atol, fused_err ? ctx->zc_d + 2 : (double*)nullptr);
+                                           w.ynew, d, w.flags, w.out, error_const[order], rtol, atol, fused_err ? ctx->zc_d + 2 : (double*)nullptr, w.plan, w.Cr);
                         LAUNCH_OK(ctx);
                     } else {
                     hipLaunchKernelGGL(bdf::newton_rhs_kernel, gn, b256, 0, ctx->stream, f, psi, d, N, c, w.rhs_r, w.flags);
@@ -2536,6 +2564,7 @@ extern "C" int marl_sweep_radau_events_dev(marl_ctx* ctx, double* y_dev, double 
         ww.Z = w.Z; ww.W = w.W; ww.F = w.F; ww.Q = w.Q; ww.YS = w.YS; ww.fac = w.fac; ww.h = w.h; ww.yscale = w.yscale; ww.maxdiff = w.maxdiff; ww.scl = w.scl;
         ww.hnew = w.hnew; ww.Jraw = w.Jraw; ww.YP = w.YP; ww.FN = w.FN; ww.J = w.J; ww.rhs_r = w.rhs_r; ww.rhs_c = w.rhs_c; ww.small = w.small; ww.groups = w.groups;
         ww.Sr = w.Sr; ww.Sc = w.Sc; ww.ng = w.ng; ww.nlevels = w.nlevels; ww.zs = zs;
+        ww.plan = w.plan; ww.Cr = w.Cr; ww.Cc = w.Cc;
         if (hipMalloc((void**)&wg_next, sizeof(unsigned) * (size_t)(2 + 2 * B)) != hipSuccess) { wg_next = nullptr; cleanup(); return fail(ctx, -3, "allocation failed"); }
     }
     // nrun < 0: the pass visits every instance; else the instances run_list[0 .. nrun) (those the last pass handed back)
@@ -2637,6 +2666,21 @@ extern "C" int marl_sweep_radau_events_dev(marl_ctx* ctx, double* y_dev, double 
                 RB_OK();
             }
         }
+        if (nL && w.cr_k) {   // cyclic reduction in front of PCR (small grids; radau_alloc): levels 0 .. cr_k - 1, then PCR on the rows that are left
+            hipLaunchKernelGGL(cr_init_kernel, dim3(pcr_groups((N + 1) / 2), 2, nL), b256, 0, ctx->stream, w.J, N, 0.0, c0, 1.0, w.Cr, w.Cc, Z(L_LU));
+            RB_OK();
+            for (int l = 0; l < w.cr_k; l++) {
+                const CrShape sh{w.cr_n[l], w.cr_off[l], w.cr_n[l + 1], w.cr_off[l + 1]};
+                hipLaunchKernelGGL(cr_reduce_kernel, dim3(pcr_groups(sh.n_next), 2, nL), b256, 0, ctx->stream, 0.0, c0, w.Cr, w.Cc, sh, l + 1 == w.cr_k ? 1 : 0, w.Sr, w.Sc,
+                                   Z(L_LU));
+                RB_OK();
+            }
+            const int64_t M = w.cr_n[w.cr_k];
+            for (int level = 0; level < w.nlevels; level++) {
+                hipLaunchKernelGGL(pcr_factor_kernel, dim3(pcr_groups(M), 2, nL), b256, 0, ctx->stream, w.J, M, level, 0.0, c0, w.Sr, w.Sc, Z(L_LU));
+                RB_OK();
+            }
+        } else
         if (nL)
             for (int level = -1; level < w.nlevels; level++) {
                 hipLaunchKernelGGL(pcr_factor_kernel, dim3((unsigned)((N + PCR_CELLS_PER_BLOCK - 1) / PCR_CELLS_PER_BLOCK), 2, nL), b256, 0, ctx->stream, w.J, N, level, 0.0, c0,
@@ -2664,7 +2708,7 @@ extern "C" int marl_sweep_radau_events_dev(marl_ctx* ctx, double* y_dev, double 
             }
             if (n <= PCR_FUSED_MAX && ctx->radau_fused_solve) {
                 hipLaunchKernelGGL(pcr_solve_fused_kernel, dim3(1, which == 0 ? 2 : 1, cnt), dim3(PCR_FUSED_THREADS), 0, ctx->stream, N, w.nlevels, 0, w.Sr, w.Sc, w.rhs_r,
-                                   w.rhs_r, w.rhs_c, w.rhs_c, zb);
+                                   w.rhs_r, w.rhs_c, w.rhs_c, zb, w.plan, w.Cr, w.Cc);
                 RB_OK();
             } else {
                 const double* in_r = w.rhs_r;

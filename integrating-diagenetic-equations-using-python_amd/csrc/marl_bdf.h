@@ -107,7 +107,8 @@ __global__ void __launch_bounds__(radau::PCR_FUSED_THREADS) newton_fused_kernel(
                                                                                   int nlevels, radau::PcrSystem<double> Sr, const double* __restrict__ scale,
                                                                                   double* __restrict__ ynew, double* __restrict__ d, int32_t* __restrict__ flags,
                                                                                   double* __restrict__ out, double err_coef = 0.0, double rtol = 0.0, double atol = 0.0,
-                                                                                  double* __restrict__ err_out = nullptr)
+                                                                                  double* __restrict__ err_out = nullptr, radau::CrPlan pl = radau::CrPlan{},
+                                                                                  radau::CrSystem<double> Cr = radau::CrSystem<double>{})
 {
     using namespace radau;
     __shared__ double lds[2 * PCR_FUSED_MAX + PCR_FUSED_MAX];   // ping-pong right-hand sides + the solution
@@ -124,16 +125,20 @@ __global__ void __launch_bounds__(radau::PCR_FUSED_THREADS) newton_fused_kernel(
     // for out[0] and then trusts the flag.  A workgroup barrier does not order stores of different waves to system memory, so the
     // flag is folded through the barrier and written by the one thread that later writes out[0], with a system-scope fence between.
     const int any_bad = __syncthreads_or(bad);
-    int cur = 0;
-    for (int level = 0; level < nlevels; level++) {
-        const double* b = lds + cur * PCR_FUSED_MAX;
-        double* o = lds + (cur ^ 1) * PCR_FUSED_MAX;
-        for (int k = threadIdx.x; k < n; k += PCR_FUSED_THREADS) pcr_solve_row<double>(N, k, level, nlevels, Sr, b, o);
-        __syncthreads();
-        cur ^= 1;
-    }
     double* x = lds + 2 * PCR_FUSED_MAX;
-    for (int k = threadIdx.x; k < n; k += PCR_FUSED_THREADS) pcr_solve_row<double>(N, k, nlevels, nlevels, Sr, lds + cur * PCR_FUSED_MAX, x);
+    if (pl.k == 0) {
+        int cur = 0;
+        for (int level = 0; level < nlevels; level++) {
+            const double* b = lds + cur * PCR_FUSED_MAX;
+            double* o = lds + (cur ^ 1) * PCR_FUSED_MAX;
+            for (int k = threadIdx.x; k < n; k += PCR_FUSED_THREADS) pcr_solve_row<double>(N, k, level, nlevels, Sr, b, o);
+            __syncthreads();
+            cur ^= 1;
+        }
+        for (int k = threadIdx.x; k < n; k += PCR_FUSED_THREADS) pcr_solve_row<double>(N, k, nlevels, nlevels, Sr, lds + cur * PCR_FUSED_MAX, x);
+    } else {
+        crpcr_solve_all<double>(pl, N, nlevels, Cr, Sr, nullptr, x, lds, true);   // (the right-hand side is in lds already)
+    }
     __syncthreads();
     double ss = 0;
     for (int kk = threadIdx.x; kk < n; kk += PCR_FUSED_THREADS) {   // (newton_update_kernel with one workgroup)

@@ -30,7 +30,8 @@ __global__ void __launch_bounds__(radau::WG_THREADS) solve_wg_kernel(int mode, c
                                                                       double* __restrict__ ypred, double* __restrict__ psi, double* __restrict__ scale,
                                                                       double* __restrict__ ynew, double* __restrict__ d, double* __restrict__ f, int64_t N, double c,
                                                                       int nlevels, radau::PcrSystem<double> Sr, const DevConsts* __restrict__ consts,
-                                                                      double newton_tol, double err_coef, double rtol, double atol, double* __restrict__ words)
+                                                                      double newton_tol, double err_coef, double rtol, double atol, double* __restrict__ words,
+                                                                      radau::CrPlan pl = radau::CrPlan{}, radau::CrSystem<double> Cr = radau::CrSystem<double>{})
 {
     using namespace radau;
     __shared__ SolveBuf buf;
@@ -85,16 +86,20 @@ __global__ void __launch_bounds__(radau::WG_THREADS) solve_wg_kernel(int mode, c
         }
         any_bad = __syncthreads_or(bad);
         if (any_bad) break;   // (bdf.py:44-45; uniform)
-        int cur = 0;
-        for (int level = 0; level < nlevels; level++) {
-            const double* b = lds + cur * PCR_FUSED_MAX;
-            double* o = lds + (cur ^ 1) * PCR_FUSED_MAX;
-            for (int kk = tid; kk < n; kk += WG_THREADS) pcr_solve_row<double>(N, kk, level, nlevels, Sr, b, o);
-            __syncthreads();
-            cur ^= 1;
-        }
         double* x = lds + 2 * PCR_FUSED_MAX;
-        for (int kk = tid; kk < n; kk += WG_THREADS) pcr_solve_row<double>(N, kk, nlevels, nlevels, Sr, lds + cur * PCR_FUSED_MAX, x);
+        if (pl.k == 0) {
+            int cur = 0;
+            for (int level = 0; level < nlevels; level++) {
+                const double* b = lds + cur * PCR_FUSED_MAX;
+                double* o = lds + (cur ^ 1) * PCR_FUSED_MAX;
+                for (int kk = tid; kk < n; kk += WG_THREADS) pcr_solve_row<double>(N, kk, level, nlevels, Sr, b, o);
+                __syncthreads();
+                cur ^= 1;
+            }
+            for (int kk = tid; kk < n; kk += WG_THREADS) pcr_solve_row<double>(N, kk, nlevels, nlevels, Sr, lds + cur * PCR_FUSED_MAX, x);
+        } else {
+            crpcr_solve_all<double>(pl, N, nlevels, Cr, Sr, nullptr, x, lds, true);   // (the right-hand side is in lds already)
+        }
         __syncthreads();
         double ss = 0;
         for (int kk = tid; kk < n; kk += WG_THREADS) {   // (newton_update_kernel with one workgroup)

@@ -608,17 +608,149 @@ __device__ __forceinline__ void pcr_solve_all(int64_t N, int nlevels, const PcrS
     for (int k = threadIdx.x; k < n; k += PCR_FUSED_THREADS) pcr_solve_row<T>(N, k, nlevels, nlevels, S, lds + cur * PCR_FUSED_MAX, bout);
 }
 
+// ---- block CYCLIC reduction in front of PCR (marl_radau_cr.h has the story and the factor kernels): storage and the row recurrences
+// of a solve, here because the one-launch solve kernels below use them too ----------------------------------------------------
+// One system (real or complex) over all levels.  Level l has n_l rows in position space; in every array its rows start at row off_l.
+template <class T>
+struct CrSystem {
+    T *L, *D, *U;        // the level's blocks [row][25] (levels 0 .. k-1; level k is set 0 of the compact PcrSystem)
+    T *Dinv, *P, *Q;     // rows eliminated at their level (even positions): D^-1, -D^-1 L, -D^-1 U
+    T *alpha, *gamma;    // rows that stay (odd positions)
+    T *b;                // right-hand sides, then solutions [row][5] of levels 1 .. k (level 0 is the caller's vector)
+};
+struct CrShape {
+    int64_t n_cur, off_cur, n_next, off_next;
+};
+
+// the levels of a SMALL system (one-launch solves; k <= CR_WG_MAX_LEVELS): level l has n[l] rows from row off[l]; n[k] rows go to PCR
+constexpr int CR_WG_MAX_LEVELS = 3;
+struct CrPlan {
+    int k;   // 0: no cyclic reduction (PCR over all rows)
+    int64_t n[CR_WG_MAX_LEVELS + 1], off[CR_WG_MAX_LEVELS + 1];
+};
+template <class T>
+__device__ __forceinline__ CrSystem<T> z_shift_cr(CrSystem<T> C, const ZBatch& B)
+{
+    C.L = z_shift(C.L, B); C.D = z_shift(C.D, B); C.U = z_shift(C.U, B); C.Dinv = z_shift(C.Dinv, B); C.P = z_shift(C.P, B); C.Q = z_shift(C.Q, B);
+    C.alpha = z_shift(C.alpha, B); C.gamma = z_shift(C.gamma, B); C.b = z_shift(C.b, B);
+    return C;
+}
+
+// one thread per unknown of level l + 1:  b'_q = b_p + alpha_p b_{p-1} + gamma_p b_{p+1},  p = 2 q + 1
+template <class T>
+__device__ __forceinline__ void cr_rhs_row(const CrSystem<T>& C, CrShape sh, int64_t kk, const T* __restrict__ bin, T* __restrict__ bout)
+{
+    const int64_t q = kk / NF;
+    const int r = (int)(kk % NF);
+    const int64_t p = 2 * q + 1;
+    T acc = bin[p * NF + r];
+    const T* al = C.alpha + (sh.off_cur + p) * 25 + r * NF;
+#pragma unroll
+    for (int k = 0; k < NF; k++) acc = madd(acc, al[k], bin[(p - 1) * NF + k]);
+    if (p + 1 < sh.n_cur) {
+        const T* ga = C.gamma + (sh.off_cur + p) * 25 + r * NF;
+#pragma unroll
+        for (int k = 0; k < NF; k++) acc = madd(acc, ga[k], bin[(p + 1) * NF + k]);
+    }
+    bout[kk] = acc;
+}
+
+// Back-substitution value of row p of level l (b: the level's right-hand sides, xn: the solution of level l + 1): odd positions take their
+// value from xn, even ones  x_p = D_p^-1 b_p + P_p x_{p-1} + Q_p x_{p+1}.
+template <class T>
+__device__ __forceinline__ T cr_back_value(const CrSystem<T>& C, CrShape sh, int64_t p, int r, const T* __restrict__ b, const T* __restrict__ xn)
+{
+    const int64_t q = p >> 1;
+    if (p & 1) return xn[q * NF + r];
+    const T* di = C.Dinv + (sh.off_cur + p) * 25 + r * NF;
+    T acc = mul1(di[0], b[p * NF]);
+#pragma unroll
+    for (int k = 1; k < NF; k++) acc = madd(acc, di[k], b[p * NF + k]);
+    if (q >= 1) {
+        const T* pr = C.P + (sh.off_cur + p) * 25 + r * NF;
+#pragma unroll
+        for (int k = 0; k < NF; k++) acc = madd(acc, pr[k], xn[(q - 1) * NF + k]);
+    }
+    if (q < sh.n_next) {
+        const T* qr = C.Q + (sh.off_cur + p) * 25 + r * NF;
+#pragma unroll
+        for (int k = 0; k < NF; k++) acc = madd(acc, qr[k], xn[q * NF + k]);
+    }
+    return acc;
+}
+
+
+// A whole solve of a small system in ONE workgroup: right-hand sides down the k cyclic-reduction levels, PCR on the rows that are
+// left, solutions back up - all vectors in LDS (level l at lds + 5 off[l]; the PCR ping-pong partner behind the last level:
+// 5 (off[k] + 2 n[k]) <= 2 PCR_FUSED_MAX elements for N <= 409, k <= 3).  Why not PCR alone: the chain of levels in one workgroup is
+// bound by the BYTES of factor rows that must pass through one compute unit's 64 B / clock (tools/lab_src/solve_chain_probe.hip:
+// 1.1 us per level of 80 KB, 0.43 us without the loads, 0.04 us for the barrier) - PCR reads 8 levels x N rows x 400 B, two or
+// three levels of cyclic reduction in front of it cut that 2.4 - 2.8 times.  pl.k == 0: pcr_solve_all.  Row arithmetic: cr_rhs_row,
+// pcr_solve_row, cr_back_value - the launch kernels' (bit-identical to a level-by-level solve).  In place (bout == bin) is fine.
+template <class T>
+__device__ __forceinline__ void crpcr_solve_all(const CrPlan& pl, int64_t N, int nlevels, const CrSystem<T>& C, const PcrSystem<T>& S, const T* bin, T* bout, T* lds,
+                                                bool staged = false)   // staged (pl.k > 0 only): the right-hand side is in lds[0 .. 5 N) already
+{
+    if (pl.k == 0) {
+        pcr_solve_all<T>(N, nlevels, S, bin, bout, lds);
+        return;
+    }
+    const int n = (int)(NF * N);
+    if (!staged)
+        for (int kk = threadIdx.x; kk < n; kk += PCR_FUSED_THREADS) lds[kk] = bin[kk];
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < CR_WG_MAX_LEVELS; l++) {
+        if (l < pl.k) {
+            const CrShape sh{pl.n[l], pl.off[l], pl.n[l + 1], pl.off[l + 1]};
+            const int cnt = (int)(NF * sh.n_next);
+            for (int kk = threadIdx.x; kk < cnt; kk += PCR_FUSED_THREADS) cr_rhs_row<T>(C, sh, kk, lds + sh.off_cur * NF, lds + sh.off_next * NF);
+            __syncthreads();
+        }
+    }
+    const int64_t M = pl.n[pl.k];
+    const int m = (int)(NF * M);
+    T* cur = lds + pl.off[pl.k] * NF;
+    T* oth = cur + m;
+    for (int level = 0; level <= nlevels; level++) {
+        for (int kk = threadIdx.x; kk < m; kk += PCR_FUSED_THREADS) pcr_solve_row<T>(M, kk, level, nlevels, S, cur, oth);
+        __syncthreads();
+        T* sw = cur; cur = oth; oth = sw;
+    }
+    const T* xn = cur;   // the solution of the compact system
+#pragma unroll
+    for (int l = CR_WG_MAX_LEVELS - 1; l >= 0; l--) {
+        if (l < pl.k) {
+            const CrShape sh{pl.n[l], pl.off[l], pl.n[l + 1], pl.off[l + 1]};
+            T* b = lds + sh.off_cur * NF;
+            const int cnt = (int)(NF * sh.n_cur);
+            T v0 = T{}, v1 = T{};   // (5 n_cur <= 2 x 1024: at most two rows' worth per thread; formed before any is stored - in place)
+            const int k0 = threadIdx.x, k1 = threadIdx.x + PCR_FUSED_THREADS;
+            if (k0 < cnt) v0 = cr_back_value<T>(C, sh, k0 / NF, k0 % NF, b, xn);
+            if (k1 < cnt) v1 = cr_back_value<T>(C, sh, k1 / NF, k1 % NF, b, xn);
+            __syncthreads();
+            if (k0 < cnt) b[k0] = v0;
+            if (k1 < cnt) b[k1] = v1;
+            __syncthreads();
+            xn = b;
+        }
+    }
+    for (int kk = threadIdx.x; kk < n; kk += PCR_FUSED_THREADS) bout[kk] = lds[kk];
+}
+
 // blockIdx.y + first: which system (0 real, 1 complex); in place (bout == bin) is fine: the input is staged in LDS first
 __global__ void __launch_bounds__(PCR_FUSED_THREADS) pcr_solve_fused_kernel(int64_t N, int nlevels, int first, PcrSystem<double> Sr, PcrSystem<cplx> Sc,
                                                                             const double* bin_r, double* bout_r, const cplx* bin_c, cplx* bout_c,
-                                                                            ZBatch B = ZBatch{0, nullptr, 0, 0, nullptr})
+                                                                            ZBatch B = ZBatch{0, nullptr, 0, 0, nullptr}, CrPlan pl = CrPlan{},
+                                                                            CrSystem<double> Cr = CrSystem<double>{}, CrSystem<cplx> Cc = CrSystem<cplx>{})
 {
     if (z_masked_out(B)) return;
     Sr = z_shift_system(Sr, B); Sc = z_shift_system(Sc, B);
+    Cr = z_shift_cr(Cr, B); Cc = z_shift_cr(Cc, B);
     bin_r = z_shift(bin_r, B); bout_r = z_shift(bout_r, B); bin_c = z_shift(bin_c, B); bout_c = z_shift(bout_c, B);
     __shared__ cplx lds[2 * PCR_FUSED_MAX];   // (the real system uses half of the bytes)
-    if (blockIdx.y + first == 0) pcr_solve_all<double>(N, nlevels, Sr, bin_r, bout_r, reinterpret_cast<double*>(lds));
-    else pcr_solve_all<cplx>(N, nlevels, Sc, bin_c, bout_c, lds);
+    if (blockIdx.y + first == 0) crpcr_solve_all<double>(pl, N, nlevels, Cr, Sr, bin_r, bout_r, reinterpret_cast<double*>(lds));
+    else crpcr_solve_all<cplx>(pl, N, nlevels, Cc, Sc, bin_c, bout_c, lds);
 }
 
 // ---- element-wise pieces of solve_collocation_system (radau.py:47-130) and _step_impl (:404-537) -------------------------
@@ -695,7 +827,8 @@ __global__ void __launch_bounds__(PCR_FUSED_THREADS) newton_fused_kernel(const d
                                                                          int nlevels, PcrSystem<double> Sr, PcrSystem<cplx> Sc, const double* __restrict__ scale,
                                                                          double* __restrict__ W, double* __restrict__ Z, double* __restrict__ YS,
                                                                          double* __restrict__ rhs_r, cplx* __restrict__ rhs_c, int32_t* __restrict__ flags,
-                                                                         double* __restrict__ out)
+                                                                         double* __restrict__ out, CrPlan pl = CrPlan{}, CrSystem<double> Cr = CrSystem<double>{},
+                                                                         CrSystem<cplx> Cc = CrSystem<cplx>{})
 {
     __shared__ cplx lds[2 * PCR_FUSED_MAX];   // (the real system uses half of the bytes)
     __shared__ double red[PCR_FUSED_THREADS];
@@ -711,9 +844,9 @@ __global__ void __launch_bounds__(PCR_FUSED_THREADS) newton_fused_kernel(const d
         rhs_c[kk] = fc - M_c * w;
     }
     const int any_bad = __syncthreads_or(bad);
-    pcr_solve_all<double>(N, nlevels, Sr, rhs_r, rhs_r, reinterpret_cast<double*>(lds));
+    crpcr_solve_all<double>(pl, N, nlevels, Cr, Sr, rhs_r, rhs_r, reinterpret_cast<double*>(lds));
     __syncthreads();
-    pcr_solve_all<cplx>(N, nlevels, Sc, rhs_c, rhs_c, lds);
+    crpcr_solve_all<cplx>(pl, N, nlevels, Cc, Sc, rhs_c, rhs_c, lds);
     __syncthreads();
     double ss = 0;
     for (int64_t kk = threadIdx.x; kk < n; kk += PCR_FUSED_THREADS) {   // newton_update_kernel, one workgroup

@@ -24,17 +24,8 @@ namespace radau {
 constexpr int CR_MAX_LEVELS = 24;
 constexpr int CR_ROWS_PER_BLOCK = 64;   // back-substitution: 64 rows x 5 unknowns = 320 threads, so that no row straddles two workgroups
 
-// One system (real or complex) over all levels.  Level l has n_l rows in position space; in every array its rows start at row off_l.
-template <class T>
-struct CrSystem {
-    T *L, *D, *U;        // the level's blocks [row][25] (levels 0 .. k-1; level k is set 0 of the compact PcrSystem)
-    T *Dinv, *P, *Q;     // rows eliminated at their level (even positions): D^-1, -D^-1 L, -D^-1 U
-    T *alpha, *gamma;    // rows that stay (odd positions)
-    T *b;                // right-hand sides, then solutions [row][5] of levels 1 .. k (level 0 is the caller's vector)
-};
-struct CrShape {
-    int64_t n_cur, off_cur, n_next, off_next;
-};
+// (CrSystem / CrShape / CrPlan and the row recurrences of a solve - cr_rhs_row, cr_back_value - live in marl_radau.h, in front of the
+//  one-launch solve kernels that use them.)
 
 // level 0 from the Jacobian: group g builds the blocks of cells 2g (eliminated at level 0: inverse and the two back-substitution blocks)
 // and 2g + 1.  The matrix is mu I - jscale J as in pcr_factor_group.
@@ -75,9 +66,13 @@ __device__ void cr_init_group(const double* __restrict__ J, int64_t N, T mu, dou
 }
 
 // blockIdx.y: 0 real system, 1 complex system
+// blockIdx.z: instance of a sweep (ZBatch, as pcr_factor_kernel: per-instance mu from the instance's controller)
 __global__ void __launch_bounds__(256) cr_init_kernel(const double* __restrict__ J, int64_t N, double mu_r, cplx mu_c, double jscale, CrSystem<double> Cr,
-                                                      CrSystem<cplx> Cc)
+                                                      CrSystem<cplx> Cc, ZBatch B = ZBatch{0, nullptr, 0, 0, nullptr})
 {
+    if (z_masked_out(B)) return;
+    if (B.act) { const RadauCtl* c = ctl_of(B); mu_r = c->mu_r; mu_c = cplx{c->mu_c_re, c->mu_c_im}; }
+    J = z_shift(J, B); Cr = z_shift_cr(Cr, B); Cc = z_shift_cr(Cc, B);
     __shared__ PcrStage<cplx> stage[PCR_CELLS_PER_BLOCK];   // (the real system uses the same bytes)
     const int g = threadIdx.x >> 5, e = threadIdx.x & 31;
     const int64_t i = (int64_t)blockIdx.x * PCR_CELLS_PER_BLOCK + g;
@@ -149,8 +144,11 @@ __device__ void cr_reduce_group(T mu, const CrSystem<T>& C, CrShape sh, bool las
 }
 
 __global__ void __launch_bounds__(256) cr_reduce_kernel(double mu_r, cplx mu_c, CrSystem<double> Cr, CrSystem<cplx> Cc, CrShape sh, int last,
-                                                        PcrSystem<double> Sr, PcrSystem<cplx> Sc)
+                                                        PcrSystem<double> Sr, PcrSystem<cplx> Sc, ZBatch B = ZBatch{0, nullptr, 0, 0, nullptr})
 {
+    if (z_masked_out(B)) return;
+    if (B.act) { const RadauCtl* c = ctl_of(B); mu_r = c->mu_r; mu_c = cplx{c->mu_c_re, c->mu_c_im}; }
+    Cr = z_shift_cr(Cr, B); Cc = z_shift_cr(Cc, B); Sr = z_shift_system(Sr, B); Sc = z_shift_system(Sc, B);
     __shared__ PcrStage<cplx> stage[PCR_CELLS_PER_BLOCK];
     const int g = threadIdx.x >> 5, e = threadIdx.x & 31;
     const int64_t i = (int64_t)blockIdx.x * PCR_CELLS_PER_BLOCK + g;
@@ -166,25 +164,6 @@ __global__ void __launch_bounds__(256) cr_reduce_kernel(double mu_r, cplx mu_c, 
 }
 
 // ---- a solve: right-hand sides down the levels, the compact system by PCR (marl_radau.h), solutions back up ------------------------
-// one thread per unknown of level l + 1:  b'_q = b_p + alpha_p b_{p-1} + gamma_p b_{p+1},  p = 2 q + 1
-template <class T>
-__device__ __forceinline__ void cr_rhs_row(const CrSystem<T>& C, CrShape sh, int64_t kk, const T* __restrict__ bin, T* __restrict__ bout)
-{
-    const int64_t q = kk / NF;
-    const int r = (int)(kk % NF);
-    const int64_t p = 2 * q + 1;
-    T acc = bin[p * NF + r];
-    const T* al = C.alpha + (sh.off_cur + p) * 25 + r * NF;
-#pragma unroll
-    for (int k = 0; k < NF; k++) acc = madd(acc, al[k], bin[(p - 1) * NF + k]);
-    if (p + 1 < sh.n_cur) {
-        const T* ga = C.gamma + (sh.off_cur + p) * 25 + r * NF;
-#pragma unroll
-        for (int k = 0; k < NF; k++) acc = madd(acc, ga[k], bin[(p + 1) * NF + k]);
-    }
-    bout[kk] = acc;
-}
-
 // blockIdx.y: 0 real system, 1 complex system.  b0_*: the level-0 vectors (the caller's right-hand sides); deeper levels live in C.b.
 __global__ void __launch_bounds__(256) cr_rhs_kernel(CrSystem<double> Cr, CrSystem<cplx> Cc, CrShape sh, int level, const double* __restrict__ b0_r,
                                                      const cplx* __restrict__ b0_c)
@@ -195,31 +174,8 @@ __global__ void __launch_bounds__(256) cr_rhs_kernel(CrSystem<double> Cr, CrSyst
     else cr_rhs_row<cplx>(Cc, sh, kk, level == 0 ? b0_c : Cc.b + sh.off_cur * NF, Cc.b + sh.off_next * NF);
 }
 
-// Back-substitution of level l, IN PLACE in its right-hand side vector b (xn: the solution of level l + 1): odd positions take their
-// value from xn, even ones  x_p = D_p^-1 b_p + P_p x_{p-1} + Q_p x_{p+1}.  Every thread forms its value, THEN (barrier) all store: a
-// row's five threads read each other's b.
-template <class T>
-__device__ __forceinline__ T cr_back_value(const CrSystem<T>& C, CrShape sh, int64_t p, int r, const T* __restrict__ b, const T* __restrict__ xn)
-{
-    const int64_t q = p >> 1;
-    if (p & 1) return xn[q * NF + r];
-    const T* di = C.Dinv + (sh.off_cur + p) * 25 + r * NF;
-    T acc = mul1(di[0], b[p * NF]);
-#pragma unroll
-    for (int k = 1; k < NF; k++) acc = madd(acc, di[k], b[p * NF + k]);
-    if (q >= 1) {
-        const T* pr = C.P + (sh.off_cur + p) * 25 + r * NF;
-#pragma unroll
-        for (int k = 0; k < NF; k++) acc = madd(acc, pr[k], xn[(q - 1) * NF + k]);
-    }
-    if (q < sh.n_next) {
-        const T* qr = C.Q + (sh.off_cur + p) * 25 + r * NF;
-#pragma unroll
-        for (int k = 0; k < NF; k++) acc = madd(acc, qr[k], xn[q * NF + k]);
-    }
-    return acc;
-}
-
+// Back-substitution of level l, IN PLACE in its right-hand side vector b (cr_back_value, marl_radau.h): every thread forms its value,
+// THEN (barrier) all store - a row's five threads read each other's b.
 __global__ void __launch_bounds__(CR_ROWS_PER_BLOCK* NF) cr_back_kernel(CrSystem<double> Cr, CrSystem<cplx> Cc, CrShape sh, int level, double* b0_r, cplx* b0_c)
 {
     const int64_t p = (int64_t)blockIdx.x * CR_ROWS_PER_BLOCK + threadIdx.x / NF;

@@ -45,6 +45,10 @@ struct WgWork {
     PcrSystem<cplx> Sc;
     int ng, nlevels;
     int64_t zs;
+    // cyclic reduction in front of PCR (hybrid modes: the launch kernels factorise, the solves here follow; plan.k == 0: PCR alone)
+    CrPlan plan;
+    CrSystem<double> Cr;
+    CrSystem<cplx> Cc;
 };
 
 template <class P>
@@ -56,6 +60,14 @@ __device__ __forceinline__ PcrSystem<T> wg_at(PcrSystem<T> S, int64_t off)
     for (int k = 0; k < 2; k++) { S.L[k] = wg_at(S.L[k], off); S.D[k] = wg_at(S.D[k], off); S.U[k] = wg_at(S.U[k], off); S.Dinv[k] = wg_at(S.Dinv[k], off); S.b[k] = wg_at(S.b[k], off); }
     S.alpha = wg_at(S.alpha, off); S.gamma = wg_at(S.gamma, off);
     return S;
+}
+
+template <class T>
+__device__ __forceinline__ CrSystem<T> wg_at(CrSystem<T> C, int64_t off)
+{
+    C.L = wg_at(C.L, off); C.D = wg_at(C.D, off); C.U = wg_at(C.U, off); C.Dinv = wg_at(C.Dinv, off); C.P = wg_at(C.P, off); C.Q = wg_at(C.Q, off);
+    C.alpha = wg_at(C.alpha, off); C.gamma = wg_at(C.gamma, off); C.b = wg_at(C.b, off);
+    return C;
 }
 
 // LDS of the workgroup: one buffer reused by the phases (factorisation stage / solve right-hand sides / reductions), the log / exp
@@ -371,9 +383,9 @@ __global__ void __launch_bounds__(WG_THREADS) radau_wg_kernel(RadauCtl* __restri
                     if (bad) s_nonfinite = 1;
                 }
                 __syncthreads();
-                pcr_solve_all<double>(N, w.nlevels, wg_at(w.Sr, off), rhs_r, rhs_r, reinterpret_cast<double*>(buf.solve));
+                crpcr_solve_all<double>(w.plan, N, w.nlevels, wg_at(w.Cr, off), wg_at(w.Sr, off), rhs_r, rhs_r, reinterpret_cast<double*>(buf.solve));
                 __syncthreads();
-                pcr_solve_all<cplx>(N, w.nlevels, wg_at(w.Sc, off), rhs_c, rhs_c, buf.solve);
+                crpcr_solve_all<cplx>(w.plan, N, w.nlevels, wg_at(w.Cc, off), wg_at(w.Sc, off), rhs_c, rhs_c, buf.solve);
                 __syncthreads();
                 double ss = 0;
                 for (int64_t kk = tid; kk < n; kk += WG_THREADS) {
@@ -406,7 +418,7 @@ __global__ void __launch_bounds__(WG_THREADS) radau_wg_kernel(RadauCtl* __restri
                     ynew[i] = y[i] + Z[2 * n + i];
                 }
                 __syncthreads();
-                pcr_solve_all<double>(N, w.nlevels, wg_at(w.Sr, off), rhs_r, rhs_r, reinterpret_cast<double*>(buf.solve));
+                crpcr_solve_all<double>(w.plan, N, w.nlevels, wg_at(w.Cr, off), wg_at(w.Sr, off), rhs_r, rhs_r, reinterpret_cast<double*>(buf.solve));
                 __syncthreads();
                 double ss = 0;
                 for (int64_t kk = tid; kk < n; kk += WG_THREADS) {

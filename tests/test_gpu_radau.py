@@ -442,3 +442,95 @@ def test_run_sweep_radau_driver_on_the_gpu(torch_cuda_radau):
     eq.close()
     assert list(status) == [0] * 4 and np.all(t == 1.0)
     assert np.array_equal(y, yd.cpu().numpy()) and list(acc) == [r.n_accepted for r in res]
+
+
+def _forced_small_cr(eq, levels=3):
+    eq.set_option("radau_cr_small", levels)
+    eq.set_option("radau_cr_small_min_n", 32)
+
+
+@pytest.mark.parametrize("method", ["radau", "bdf"])
+@pytest.mark.parametrize("name", ["A", "matlab", "A_N64_tight"])
+def test_small_grid_cyclic_reduction_in_the_one_workgroup_solves(name, method):
+    """Grids solved in one workgroup (up to 409 cells) can put up to three levels of cyclic reduction in front of PCR inside the
+    one-launch solve kernels (crpcr_solve_all: the chain of levels is bound by the factor bytes that pass through one compute unit).
+    Default from 205 cells; forced here onto the goldens' grids (N = 200, 64): the single runs still take every decision scipy takes
+    (observed for 2 and 3 levels, Radau and BDF, all three cases - tools/lab: profiles/r03_lab_radau_wg.log), and the ways of running
+    the same arithmetic - one launch per level, one launch per solve, one launch per Newton iteration / per solve_bdf_system - agree
+    bit for bit."""
+    g, p, eq = _model(name)
+    gold = g if method == "radau" else np.load(f"{GOLDEN}/bdf_traj_{name}.npz")
+    _forced_small_cr(eq)
+    run = eq.integrate_radau if method == "radau" else eq.integrate_bdf
+    out = []
+    for fused, wg in ((1, 1), (0, 1), (2, 1), (1, 0)):
+        eq.set_option("radau_fused_solve", fused)
+        eq.set_option("bdf_solve_wg", wg)
+        out.append(run(g["y0"], tuple(g["t_span"]), float(g["first_step"]), float(g["rtol"]), float(g["atol"])))
+    eq.close()
+    want = (int(gold["nfev"]), int(gold["njev"]), int(gold["nlu"]), len(gold["step_times"]) - 1)
+    for r in out:
+        assert r.status == 0 and (r.nfev, r.njev, r.nlu, r.n_accepted) == want
+        assert np.array_equal(r.y_final, out[0].y_final)
+        assert all(np.array_equal(x, y) for x, y in zip(r.t_events, out[0].t_events))
+    assert np.max(np.abs(out[0].y_final - gold["y_final"])) <= 4 * STATE_TOL
+
+
+def test_small_grid_cyclic_reduction_at_409_cells_by_default():
+    """N = 409 (two unknowns per thread of the one-workgroup chain): cyclic reduction is on by default there; per-level launches, one
+    launch per solve and one launch per Newton iteration give the same bits, and plain PCR (radau_cr_small = 0) the same decisions."""
+    from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
+    N = 409
+    p = scenario("A", N)
+    y0 = np.concatenate([np.full(N, p[k]) for k in ("CAIni", "CCIni", "cCaIni", "cCO3Ini", "PhiIni")])
+    eq = LMAHeureuxPorosityDiff.from_scenario(p, device=0)
+    out = []
+    for fused, crs in ((1, 3), (0, 3), (2, 3), (1, 0)):
+        eq.set_option("radau_fused_solve", fused)
+        eq.set_option("radau_cr_small", crs)
+        out.append(eq.integrate_radau(y0, (0.0, 1.0), 1e-6, 1e-3, 1e-3))
+    eq.close()
+    a, b, c, pcr = out
+    assert a.status == pcr.status == 0
+    for r in (b, c):
+        assert (r.nfev, r.njev, r.nlu, r.n_accepted) == (a.nfev, a.njev, a.nlu, a.n_accepted) and np.array_equal(r.y_final, a.y_final)
+    assert (pcr.nfev, pcr.njev, pcr.nlu, pcr.n_accepted) == (a.nfev, a.njev, a.nlu, a.n_accepted)      # 438 / 22 / 78 / 47 both ways
+    assert np.max(np.abs(pcr.y_final - a.y_final)) < 1e-4
+
+
+def test_small_grid_cyclic_reduction_in_sweeps(torch_cuda_radau):
+    """The same levels in a sweep (batched cr_init / cr_reduce launches over the factorisation work list, crpcr_solve_all in the
+    per-instance workgroups and in the batched one-launch solves): the launch-per-action cycle and the two hybrid modes give identical
+    results; against single runs with the same setting the instances agree like two correct runs do (a knife-edge Newton test may fall
+    the other way - why N = 200 keeps plain PCR by default)."""
+    torch = torch_cuda_radau
+    from dataclasses import asdict
+    from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
+    from marlpde_amd.parameters import Map_Scenario
+    N = 200
+    base = asdict(Map_Scenario()) | {"N": N}
+    inst = [{"Phi0": 0.6, "PhiIni": 0.5, "PhiNR": 0.6}, {"Phi0": 0.5, "PhiIni": 0.5, "PhiNR": 0.5, "k3": 0.01, "k4": 0.01},
+            {"Phi0": 0.6, "PhiIni": 0.6, "PhiNR": 0.6}, {"Phi0": 0.65, "PhiIni": 0.5, "PhiNR": 0.5, "k3": 0.05, "k4": 0.05}]
+    y0 = np.stack([np.concatenate([np.full(N, (base | d)[k]) for k in ("CAIni", "CCIni", "cCaIni", "cCO3Ini", "PhiIni")]) for d in inst])
+    out = {}
+    for wg in (0, 1, 3):
+        eq = LMAHeureuxPorosityDiff.from_scenario(base, device=0, instances=inst)
+        eq.use_stream(torch.cuda.current_stream().cuda_stream)
+        eq.set_option("radau_sweep_wg", wg)
+        _forced_small_cr(eq)
+        yd = torch.from_numpy(y0).cuda()
+        res = eq.sweep_radau_device(yd.data_ptr(), (0.0, 1.0), 1e-6, 1e-3, 1e-3)
+        out[wg] = (yd.cpu().numpy(), res)
+        eq.close()
+    for b, d in enumerate(inst):
+        a, h, j = out[0][1][b], out[1][1][b], out[3][1][b]
+        assert a.status == h.status == j.status == 0
+        assert (a.nfev, a.njev, a.nlu, a.n_accepted, a.n_rejected) == (h.nfev, h.njev, h.nlu, h.n_accepted, h.n_rejected) == (j.nfev, j.njev, j.nlu, j.n_accepted, j.n_rejected)
+        assert np.max(np.abs(out[0][0][b] - out[1][0][b])) <= 1e-12 and np.array_equal(out[1][0][b], out[3][0][b])
+        one = LMAHeureuxPorosityDiff.from_scenario(base | d, device=0)
+        _forced_small_cr(one)
+        ref = one.integrate_radau(y0[b], (0.0, 1.0), 1e-6, 1e-3, 1e-3)
+        one.close()
+        for x, y in ((a.nfev, ref.nfev), (a.njev, ref.njev), (a.nlu, ref.nlu), (a.n_accepted, ref.n_accepted)):
+            assert abs(x - y) <= max(6, 0.1 * y), (b, x, y)
+        np.testing.assert_allclose(out[0][0][b], ref.y_final, rtol=0.1, atol=0.01)

@@ -35,7 +35,8 @@ if "single" in what or "bdf" in what:
             print(f"{'radau' if method == 'single' else 'bdf'} N={N}: {time.time() - t0:.4f} s, nfev {r.nfev} njev {r.njev} nlu {r.nlu} steps {r.n_accepted} status {r.status}", flush=True)
             eq.close()
 if "sweep" in what:
-    N, B, k = 200, 512, 8
+    N, B = 200, int(os.environ.get("MARL_RADAU_SWEEP_B", "512"))
+    k = max(1, round(B ** (1 / 3)))
     base = scenario("default", N)
     inst = []
     for i in range(B):
