@@ -56,8 +56,9 @@ int marl_synchronize(marl_ctx* ctx);
  *   (linear systems of the implicit path: 0 block parallel cyclic reduction - the default -, 1 sequential block Thomas),
  *   implicit_zero_copy (1, the default: marl_integrate_radau / marl_integrate_bdf read their per-iteration scalars from coherent host
  *   memory that the kernels write and the host polls; 0: a copy and a stream synchronisation per read - bit-identical),
- *   radau_fused_solve (1, the default: systems of up to 2048 unknowns run every cyclic-reduction level of a solve in one
- *   launch; 0: one launch per level - bit-identical),
+ *   radau_fused_solve (systems of up to 2048 unknowns: 0 = one launch per cyclic-reduction level; 1 = every level of a solve in one
+ *   launch; 2 = a Radau Newton iteration's linear algebra in one workgroup; 3, the default = 1 plus, for single Radau runs, two
+ *   launches per Newton iteration - all bit-identical),
  *   radau_sweep_wg (Radau sweeps of grids of up to 409 cells: 3, the default: a persistent workgroup per instance runs the instance's
  *   sequential work and its Jacobians, launch kernels over work lists do the factorisations; 1: Jacobians by launch kernels too -
  *   bit-identical; 2: everything in the workgroup; 0: one launch cycle per action),

@@ -83,7 +83,7 @@ struct marl_ctx {
     int64_t rk4_variant = -1, rk45_variant = -1, sweep_variant = -1, host_layout = LAYOUT_TILED, poll = 64;
     int64_t rk4_stream = 1;     // the fixed-step loop of one grid as ONE dataflow launch (rk4_stream_kernel): 0 never, 1 large grids, 2 always
     int64_t implicit_zero_copy = 1;  // scalar results of the implicit drivers through polled host memory (0: copy + synchronise)
-    int64_t radau_fused_solve = 1;   // small systems (5 N <= 2048): 1 = all PCR levels of a solve in one launch (BDF: the whole Newton iteration); 2 = Radau too: the whole iteration's linear algebra in one launch (bit-identical, measured SLOWER: 10.1 vs 9.0 ms - the two solves then run one after the other)
+    int64_t radau_fused_solve = 3;   // small systems (5 N <= 2048): >= 1: all levels of a solve in one launch (BDF: the whole Newton iteration / solve_bdf_system); Radau single runs: 3 (default) = two launches per Newton iteration (solves with their own right-hand sides | update + norm + the next stage derivatives), 2 = the whole iteration's linear algebra in ONE workgroup (bit-identical, measured slower: the two chains then share one compute unit), 1 = four launches; 0: one launch per level
     int64_t radau_solver = 0;   // 0: block parallel cyclic reduction (parallel over depth); 1: sequential block Thomas
     int64_t radau_cr = -1;      // single runs: levels of cyclic reduction in front of PCR; -1 = automatic (grids of >= radau_cr_min_n cells: down to a
                                 // compact system that fits the one-launch solve with one unknown per thread), 0 = none
@@ -342,7 +342,7 @@ int marl_set_option(marl_ctx* ctx, const char* name, int64_t value)
     else if (n == "radau_cr_small_min_n") ctx->radau_cr_small_min_n = std::max<int64_t>(value, 32);
     else if (n == "radau_cr_tail") ctx->radau_cr_tail = value ? 1 : 0;
     else if (n == "bdf_solve_wg") ctx->bdf_solve_wg = value ? 1 : 0;
-    else if (n == "radau_fused_solve") ctx->radau_fused_solve = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (n == "radau_fused_solve") ctx->radau_fused_solve = value < 0 ? 0 : (value > 3 ? 3 : value);
     else if (n == "radau_sweep_wg") ctx->radau_sweep_wg = value < 0 ? 0 : (value > 3 ? 3 : value);
     else if (n == "implicit_zero_copy") ctx->implicit_zero_copy = value ? 1 : 0;
     else if (n == "rk4_stream") ctx->rk4_stream = value < 0 ? 0 : (value > 2 ? 2 : value);
@@ -1903,10 +1903,26 @@ int radau_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_st
                 double dW_norm_old = -1;
                 rate = -1;
                 int k;
+                // small grids, radau_fused_solve = 3 (default there): two launches per iteration - the solve workgroups assemble their own
+                // right-hand sides, the update workgroup evaluates the next iteration's stage derivatives (marl_radau_wg.h)
+                const bool two_launch = w.pcr && (!w.cr_k || w.plan.k) && n <= radau::PCR_FUSED_MAX && ctx->radau_fused_solve == 3 && ctx->zc_on;
                 for (k = 0; k < NEWTON_MAXITER; k++) {
-                    if (int rc = launch_rhs(ctx, w.YS, w.F, LAYOUT_FIELD_MAJOR, 3)) return rc;
+                    if (!two_launch || k == 0)
+                        if (int rc = launch_rhs(ctx, w.YS, w.F, LAYOUT_FIELD_MAJOR, 3)) return rc;
                     st->nfev += 3;
-                    if (w.pcr && (!w.cr_k || w.plan.k) && n <= radau::PCR_FUSED_MAX && ctx->radau_fused_solve >= 2) {   // right-hand sides + both solves + update + norm: one launch
+                    if (two_launch) {
+                        hipLaunchKernelGGL(radau::newton_solve2_kernel, dim3(1, 2), dim3(radau::PCR_FUSED_THREADS), 0, ctx->stream, w.F, w.W, N, M_real, M_c, w.nlevels, w.Sr,
+                                           w.Sc, w.rhs_r, w.rhs_c, w.flags, w.plan, w.Cr, w.Cc);
+                        LAUNCH_OK(ctx);
+                        if (ctx->var_dphi)
+                            hipLaunchKernelGGL(radau::newton_update_rhs_kernel<true>, dim3(1), dim3(radau::WG_THREADS), 0, ctx->stream, w.y, w.rhs_r, w.rhs_c, w.scale, N, w.W,
+                                               w.Z, w.YS, w.F, ctx->dconsts, w.out);
+                        else
+                            hipLaunchKernelGGL(radau::newton_update_rhs_kernel<false>, dim3(1), dim3(radau::WG_THREADS), 0, ctx->stream, w.y, w.rhs_r, w.rhs_c, w.scale, N, w.W,
+                                               w.Z, w.YS, w.F, ctx->dconsts, w.out);
+                        LAUNCH_OK(ctx);
+                    } else
+                    if (w.pcr && (!w.cr_k || w.plan.k) && n <= radau::PCR_FUSED_MAX && ctx->radau_fused_solve == 2) {   // right-hand sides + both solves + update + norm: one launch
                         hipLaunchKernelGGL(radau::newton_fused_kernel, dim3(1), dim3(radau::PCR_FUSED_THREADS), 0, ctx->stream, w.y, w.F, N, M_real, M_c, w.nlevels, w.Sr,
                                            w.Sc, w.scale, w.W, w.Z, w.YS, w.rhs_r, w.rhs_c, w.flags, w.out, w.plan, w.Cr, w.Cc);
                         LAUNCH_OK(ctx);

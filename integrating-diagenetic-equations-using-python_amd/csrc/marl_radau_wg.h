@@ -446,5 +446,82 @@ __global__ void __launch_bounds__(WG_THREADS) radau_wg_kernel(RadauCtl* __restri
     }
 }
 
+// ---- single runs on small grids: a Newton iteration in TWO launches (option radau_fused_solve = 3) ---------------------------
+// The host-driven iteration of solve_collocation_system was four launches - stage derivatives (rhs_kernel x 3), right-hand
+// sides (newton_rhs_kernel), both solves side by side in two workgroups (pcr_solve_fused_kernel), update + norm
+// (newton_update_kernel) - and a wait.  Here the two solve workgroups assemble their own right-hand side straight into LDS
+// (newton_solve2_kernel), and the update workgroup goes on to evaluate the stage derivatives of the NEXT iteration
+// (newton_update_rhs_kernel: the norm is published first, so the host's convergence tests overlap that evaluation; when the
+// iteration was the last one the three evaluations are wasted - 600 cells).  Same per-element operations and reduction tree as the
+// kernels they replace: bit-identical (tests/test_gpu_radau.py).  Keeping real and complex chain in two workgroups matters: one
+// compute unit's memory path bounds a chain (solve_chain_probe), which is why everything-in-one-workgroup (radau_fused_solve = 2) lost.
+__global__ void __launch_bounds__(PCR_FUSED_THREADS) newton_solve2_kernel(const double* __restrict__ F, const double* __restrict__ W, int64_t N, double M_real, cplx M_c,
+                                                                          int nlevels, PcrSystem<double> Sr, PcrSystem<cplx> Sc, double* __restrict__ rhs_r,
+                                                                          cplx* __restrict__ rhs_c, int32_t* __restrict__ flags, CrPlan pl, CrSystem<double> Cr,
+                                                                          CrSystem<cplx> Cc)
+{
+    __shared__ cplx lds[2 * PCR_FUSED_MAX];   // (the real system uses half of the bytes)
+    const int64_t n = NF * N;
+    if (blockIdx.y == 0) {
+        double* l = reinterpret_cast<double*>(lds);
+        for (int64_t kk = threadIdx.x; kk < n; kk += PCR_FUSED_THREADS) {   // newton_rhs_kernel, real part
+            const int64_t i = to_field_major(kk, N);
+            const double f0 = F[i], f1 = F[n + i], f2 = F[2 * n + i];
+            if (!(isfinite(f0) && isfinite(f1) && isfinite(f2))) *flags = 1;
+            l[kk] = ((f0 * TI00 + f1 * TI01) + f2 * TI02) - M_real * W[i];
+        }
+        __syncthreads();
+        if (pl.k == 0) pcr_solve_all<double>(N, nlevels, Sr, l, rhs_r, l);   // (staged onto itself)
+        else crpcr_solve_all<double>(pl, N, nlevels, Cr, Sr, nullptr, rhs_r, l, true);
+    } else {
+        for (int64_t kk = threadIdx.x; kk < n; kk += PCR_FUSED_THREADS) {   // newton_rhs_kernel, complex part
+            const int64_t i = to_field_major(kk, N);
+            const double f0 = F[i], f1 = F[n + i], f2 = F[2 * n + i];
+            const cplx w = {W[n + i], W[2 * n + i]};
+            const cplx fc = {(f0 * TI10 + f1 * TI11) + f2 * TI12, (f0 * TI20 + f1 * TI21) + f2 * TI22};
+            lds[kk] = fc - M_c * w;
+        }
+        __syncthreads();
+        if (pl.k == 0) pcr_solve_all<cplx>(N, nlevels, Sc, lds, rhs_c, lds);
+        else crpcr_solve_all<cplx>(pl, N, nlevels, Cc, Sc, nullptr, rhs_c, lds, true);
+    }
+}
+
+template <bool VD>
+__global__ void __launch_bounds__(WG_THREADS) newton_update_rhs_kernel(const double* __restrict__ y, const double* __restrict__ rhs_r, const cplx* __restrict__ rhs_c,
+                                                                       const double* __restrict__ scale, int64_t N, double* __restrict__ W, double* __restrict__ Z,
+                                                                       double* __restrict__ YS, double* __restrict__ F, const DevConsts* __restrict__ consts,
+                                                                       double* __restrict__ out)
+{
+    __shared__ double red[WG_THREADS];
+    __shared__ double tabs[TABLE_DOUBLES];
+    const Tables T = load_tables(tabs, WG_THREADS);
+    const DevConsts& C = consts[0];
+    const HotConsts K = load_hot(&C);
+    const int64_t n = NF * N;
+    double ss = 0;
+    for (int64_t kk = threadIdx.x; kk < n; kk += WG_THREADS) {   // newton_update_kernel, one workgroup
+        const int64_t i = to_field_major(kk, N);
+        const double d0 = rhs_r[kk], d1 = rhs_c[kk].re, d2 = rhs_c[kk].im;
+        const double s = scale[i];
+        const double e0 = d0 / s, e1 = d1 / s, e2 = d2 / s;
+        ss += (e0 * e0 + e1 * e1) + e2 * e2;
+        const double w0 = W[i] + d0, w1 = W[n + i] + d1, w2 = W[2 * n + i] + d2;
+        W[i] = w0; W[n + i] = w1; W[2 * n + i] = w2;
+        const double z0 = (T00 * w0 + T01 * w1) + T02 * w2, z1 = (T10 * w0 + T11 * w1) + T12 * w2, z2 = (T20 * w0 + T21 * w1) + T22 * w2;
+        Z[i] = z0; Z[n + i] = z1; Z[2 * n + i] = z2;
+        const double yi = y[i];
+        YS[i] = yi + z0; YS[n + i] = yi + z1; YS[2 * n + i] = yi + z2;
+    }
+    red[threadIdx.x] = ss;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];   // the host's convergence tests start now ...
+    wg_rhs<VD>(YS, F, 3, N, C, K, T);        // ... while the stage derivatives of the next iteration are evaluated (the barriers above made YS visible)
+}
+
 }  // namespace radau
 }  // namespace marl

@@ -285,10 +285,12 @@ def test_radau_sweep_equals_instance_by_instance(torch_cuda_radau, oracle):
 def test_radau_fused_newton_launch_is_bit_identical(name):
     """Small systems (5 N <= 2048): the right-hand sides of both collocation systems, every cyclic-reduction level of both solves, the
     update and the norm of a Newton iteration in ONE launch (radau::newton_fused_kernel, option radau_fused_solve = 2; not the default: measured slower)
-    against the one-launch solves (1) and the per-level launches (0): the same arithmetic in the same order."""
+    against the one-launch solves (1) and the per-level launches (0): the same arithmetic in the same order.  So is the default for
+    single runs (3): two launches per iteration - the two solve workgroups assemble their own right-hand sides
+    (newton_solve2_kernel), the update workgroup evaluates the next iteration's stage derivatives (newton_update_rhs_kernel)."""
     g, p, eq = _model(name)
     out = []
-    for fused in (0, 1, 2):
+    for fused in (0, 1, 2, 3):
         eq.set_option("radau_fused_solve", fused)
         out.append(eq.integrate_radau(g["y0"], tuple(g["t_span"]), float(g["first_step"]), float(g["rtol"]), float(g["atol"])))
     eq.close()
@@ -463,7 +465,7 @@ def test_small_grid_cyclic_reduction_in_the_one_workgroup_solves(name, method):
     _forced_small_cr(eq)
     run = eq.integrate_radau if method == "radau" else eq.integrate_bdf
     out = []
-    for fused, wg in ((1, 1), (0, 1), (2, 1), (1, 0)):
+    for fused, wg in ((1, 1), (0, 1), (2, 1), (3, 1), (1, 0)):
         eq.set_option("radau_fused_solve", fused)
         eq.set_option("bdf_solve_wg", wg)
         out.append(run(g["y0"], tuple(g["t_span"]), float(g["first_step"]), float(g["rtol"]), float(g["atol"])))
@@ -485,14 +487,14 @@ def test_small_grid_cyclic_reduction_at_409_cells_by_default():
     y0 = np.concatenate([np.full(N, p[k]) for k in ("CAIni", "CCIni", "cCaIni", "cCO3Ini", "PhiIni")])
     eq = LMAHeureuxPorosityDiff.from_scenario(p, device=0)
     out = []
-    for fused, crs in ((1, 3), (0, 3), (2, 3), (1, 0)):
+    for fused, crs in ((1, 3), (0, 3), (2, 3), (3, 3), (1, 0)):
         eq.set_option("radau_fused_solve", fused)
         eq.set_option("radau_cr_small", crs)
         out.append(eq.integrate_radau(y0, (0.0, 1.0), 1e-6, 1e-3, 1e-3))
     eq.close()
-    a, b, c, pcr = out
+    a, b, c, d, pcr = out
     assert a.status == pcr.status == 0
-    for r in (b, c):
+    for r in (b, c, d):
         assert (r.nfev, r.njev, r.nlu, r.n_accepted) == (a.nfev, a.njev, a.nlu, a.n_accepted) and np.array_equal(r.y_final, a.y_final)
     assert (pcr.nfev, pcr.njev, pcr.nlu, pcr.n_accepted) == (a.nfev, a.njev, a.nlu, a.n_accepted)      # 438 / 22 / 78 / 47 both ways
     assert np.max(np.abs(pcr.y_final - a.y_final)) < 1e-4
