@@ -1967,11 +1967,21 @@ int radau_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_st
                 st->n_rejected++;
                 continue;
             }
-            // error estimate (radau.py:466-478)
-            hipLaunchKernelGGL(radau::error_rhs_kernel, gn, b256, 0, ctx->stream, w.f, w.Z, w.y, N, E3[0], E3[1], E3[2], h, w.rhs_r, w.ynew);
-            LAUNCH_OK(ctx);
-            if (int rc = radau_solve(ctx, w, false)) return rc;
-            if (int rc = radau_error_norm(ctx, w, rtol, atol)) return rc;
+            // error estimate (radau.py:466-478); small grids: one launch (error_fused_kernel)
+            const bool err_fused = w.pcr && (!w.cr_k || w.plan.k) && n <= radau::PCR_FUSED_MAX && ctx->radau_fused_solve == 3;
+            auto error_estimate = [&](const double* fvec) -> int {
+                if (err_fused) {
+                    hipLaunchKernelGGL(radau::error_fused_kernel, dim3(1), dim3(radau::PCR_FUSED_THREADS), 0, ctx->stream, fvec, w.Z, w.y, N, E3[0], E3[1], E3[2], h, w.nlevels,
+                                       w.Sr, rtol, atol, w.ynew, w.err, w.yerr, w.out, w.plan, w.Cr);
+                    LAUNCH_OK(ctx);
+                    return 0;
+                }
+                hipLaunchKernelGGL(radau::error_rhs_kernel, gn, b256, 0, ctx->stream, fvec, w.Z, w.y, N, E3[0], E3[1], E3[2], h, w.rhs_r, w.ynew);
+                LAUNCH_OK(ctx);
+                if (int rc = radau_solve(ctx, w, false)) return rc;
+                return radau_error_norm(ctx, w, rtol, atol);
+            };
+            if (int rc = error_estimate(w.f)) return rc;
             double ss;
             if (int rc = radau_read(ctx, w, &ss, nullptr)) return rc;
             error_norm = std::sqrt(ss) / std::sqrt((double)n);
@@ -1979,10 +1989,7 @@ int radau_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_st
             if (rejected && error_norm > 1) {
                 if (int rc = launch_rhs(ctx, w.yerr, w.tmp, LAYOUT_FIELD_MAJOR)) return rc;   // fun(t, y + error)
                 st->nfev++;
-                hipLaunchKernelGGL(radau::error_rhs_kernel, gn, b256, 0, ctx->stream, w.tmp, w.Z, w.y, N, E3[0], E3[1], E3[2], h, w.rhs_r, w.ynew);
-                LAUNCH_OK(ctx);
-                if (int rc = radau_solve(ctx, w, false)) return rc;
-                if (int rc = radau_error_norm(ctx, w, rtol, atol)) return rc;
+                if (int rc = error_estimate(w.tmp)) return rc;
                 if (int rc = radau_read(ctx, w, &ss, nullptr)) return rc;
                 error_norm = std::sqrt(ss) / std::sqrt((double)n);
             }
@@ -2002,7 +2009,15 @@ int radau_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_st
         { const double sf = safety * factor; factor = (sf < MAX_FACTOR) ? sf : MAX_FACTOR; }
         if (!recompute_jac && factor < 1.2) factor = 1;
         else have_lu = false;
-        if (int rc = launch_rhs(ctx, w.ynew, w.fnew, LAYOUT_FIELD_MAJOR)) return rc;
+        // small grids: f(y_new), the dense-output coefficients and the monitors of y_new in one launch (accept_fused_kernel)
+        const bool acc_fused = w.pcr && n <= radau::PCR_FUSED_MAX && ctx->radau_fused_solve == 3 && ctx->zc_on;
+        if (acc_fused) {
+            if (ctx->var_dphi)
+                hipLaunchKernelGGL(radau::accept_fused_kernel<true>, dim3(1), dim3(radau::WG_THREADS), 0, ctx->stream, w.ynew, w.fnew, w.Z, N, P, w.Q, ctx->dconsts, ctx->zc_d);
+            else
+                hipLaunchKernelGGL(radau::accept_fused_kernel<false>, dim3(1), dim3(radau::WG_THREADS), 0, ctx->stream, w.ynew, w.fnew, w.Z, N, P, w.Q, ctx->dconsts, ctx->zc_d);
+            LAUNCH_OK(ctx);
+        } else if (int rc = launch_rhs(ctx, w.ynew, w.fnew, LAYOUT_FIELD_MAJOR)) return rc;
         st->nfev++;
         if (recompute_jac) {
             if (int rc = radau_num_jac(ctx, w, w.ynew, w.fnew, atol)) return rc;
@@ -2020,14 +2035,20 @@ int radau_run(marl_ctx* ctx, RadauWork& w, double t0, double t1, double first_st
         std::swap(w.f, w.fnew);
         const double t_old = t;
         t = t_new;
-        hipLaunchKernelGGL(radau::dense_q_kernel, gn, b256, 0, ctx->stream, w.Z, n, P, w.Q);
-        LAUNCH_OK(ctx);
+        if (!acc_fused) {
+            hipLaunchKernelGGL(radau::dense_q_kernel, gn, b256, 0, ctx->stream, w.Z, n, P, w.Q);
+            LAUNCH_OK(ctx);
+        }
         have_sol = true;
         dense = {t_old, t - t_old};
         if (t - t1 >= 0) status = 0;
 
         // events (ivp.py:673-694) and t_eval (ivp.py:706-723)
-        if (int rc = radau_monitors(ctx, w.y, g_new)) return rc;
+        if (acc_fused) {
+            double marker;
+            if (int rc = radau_read(ctx, w, &marker, nullptr)) return rc;
+            for (int e = 0; e < 7; e++) g_new[e] = const_cast<const volatile double*>(ctx->zc_h)[16 + e];
+        } else if (int rc = radau_monitors(ctx, w.y, g_new)) return rc;
         for (int e = 0; e < 7; e++) {
             const bool up = g[e] <= 0 && g_new[e] >= 0, down = g[e] >= 0 && g_new[e] <= 0;
             if (up || down) {

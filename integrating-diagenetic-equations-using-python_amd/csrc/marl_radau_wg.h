@@ -523,5 +523,75 @@ __global__ void __launch_bounds__(WG_THREADS) newton_update_rhs_kernel(const dou
     wg_rhs<VD>(YS, F, 3, N, C, K, T);        // ... while the stage derivatives of the next iteration are evaluated (the barriers above made YS visible)
 }
 
+// The error estimate of a step (radau.py:466-478) in ONE launch for small grids: right-hand side fvec + Z^T E / h and y_new
+// (error_rhs_kernel) straight into LDS, the real system's solve, then err, y + err and the scaled norm (error_norm_kernel with one
+// workgroup) - three launches before.  Same operations, same reduction tree.
+__global__ void __launch_bounds__(PCR_FUSED_THREADS) error_fused_kernel(const double* __restrict__ fvec, const double* __restrict__ Z, const double* __restrict__ y,
+                                                                        int64_t N, double E0, double E1, double E2, double h, int nlevels, PcrSystem<double> Sr,
+                                                                        double rtol, double atol, double* __restrict__ ynew, double* __restrict__ err,
+                                                                        double* __restrict__ yerr, double* __restrict__ out, CrPlan pl, CrSystem<double> Cr)
+{
+    __shared__ double lds[3 * PCR_FUSED_MAX];
+    __shared__ double red[PCR_FUSED_THREADS];
+    const int64_t n = NF * N;
+    for (int64_t kk = threadIdx.x; kk < n; kk += PCR_FUSED_THREADS) {   // error_rhs_kernel
+        const int64_t i = to_field_major(kk, N);
+        const double ZE = ((Z[i] * E0 + Z[n + i] * E1) + Z[2 * n + i] * E2) / h;
+        lds[kk] = fvec[i] + ZE;
+        ynew[i] = y[i] + Z[2 * n + i];
+    }
+    __syncthreads();
+    double* x = lds + 2 * PCR_FUSED_MAX;
+    if (pl.k == 0) pcr_solve_all<double>(N, nlevels, Sr, lds, x, lds);   // (staged onto itself)
+    else crpcr_solve_all<double>(pl, N, nlevels, Cr, Sr, nullptr, x, lds, true);
+    __syncthreads();
+    double ss = 0;
+    for (int64_t kk = threadIdx.x; kk < n; kk += PCR_FUSED_THREADS) {   // error_norm_kernel, one workgroup
+        const int64_t i = to_field_major(kk, N);
+        const double e = x[kk];
+        const double a = fabs(y[i]), b = fabs(ynew[i]);
+        const double s = atol + ((a > b || a != a) ? a : b) * rtol;
+        const double q = e / s;
+        ss += q * q;
+        err[i] = e;
+        yerr[i] = y[i] + e;
+    }
+    red[threadIdx.x] = ss;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// What follows an accepted step, in ONE launch for small grids: f(y_new) (rhs_kernel), the dense-output coefficients Q = Z^T P
+// (dense_q_kernel) and the seven monitors of y_new (monitors_kernel + reduce_records_kernel: extrema, exact) - four launches before.
+// words: the zero-copy result block (marl_api.hip): g -> words[16 .. 23), then words[0] (the word the host waits for).
+template <bool VD>
+__global__ void __launch_bounds__(WG_THREADS) accept_fused_kernel(const double* __restrict__ ynew, double* __restrict__ fnew, const double* __restrict__ Z, int64_t N, P33 P,
+                                                                  double* __restrict__ Q, const DevConsts* __restrict__ consts, double* __restrict__ words)
+{
+    __shared__ double red[NQ * WG_THREADS];
+    __shared__ double tabs[TABLE_DOUBLES];
+    __shared__ double g_new[7];
+    const Tables T = load_tables(tabs, WG_THREADS);
+    const DevConsts& C = consts[0];
+    const HotConsts K = load_hot(&C);
+    const int64_t n = NF * N;
+    wg_rhs<VD>(ynew, fnew, 1, N, C, K, T);
+    for (int64_t i = threadIdx.x; i < n; i += WG_THREADS) {   // dense_q_kernel
+        const double z0 = Z[i], z1 = Z[n + i], z2 = Z[2 * n + i];
+#pragma unroll
+        for (int m = 0; m < 3; m++) Q[3 * i + m] = (z0 * P.p[0][m] + z1 * P.p[1][m]) + z2 * P.p[2][m];
+    }
+    wg_monitors(ynew, N, C, T, red, g_new);
+    if (threadIdx.x == 0) {
+        for (int e = 0; e < 7; e++) words[16 + e] = g_new[e];
+        __threadfence_system();
+        words[0] = 1.0;
+    }
+}
+
 }  // namespace radau
 }  // namespace marl
