@@ -536,3 +536,26 @@ def test_small_grid_cyclic_reduction_in_sweeps(torch_cuda_radau):
         for x, y in ((a.nfev, ref.nfev), (a.njev, ref.njev), (a.nlu, ref.nlu), (a.n_accepted, ref.n_accepted)):
             assert abs(x - y) <= max(6, 0.1 * y), (b, x, y)
         np.testing.assert_allclose(out[0][0][b], ref.y_final, rtol=0.1, atol=0.01)
+
+
+def test_radau_fused_launches_with_the_variable_porosity_diffusion(oracle):
+    """The dPhi_variable instantiations of the fused single-run launches (newton_update_rhs_kernel<true>, accept_fused_kernel<true>):
+    bit-identical to the four-launch iteration, and the run agrees with the oracle's Radau on the same parameters."""
+    from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
+    N = 200
+    p = scenario("A", N) | {"dPhi_variable": True}
+    y0 = np.concatenate([np.full(N, p[k]) for k in ("CAIni", "CCIni", "cCaIni", "cCO3Ini", "PhiIni")])
+    eq = LMAHeureuxPorosityDiff.from_scenario(p, device=0)
+    out = []
+    for fused in (1, 3):
+        eq.set_option("radau_fused_solve", fused)
+        out.append(eq.integrate_radau(y0, (0.0, 0.5), 1e-6, 1e-3, 1e-3))
+    eq.close()
+    a, b = out
+    assert (a.status, a.nfev, a.njev, a.nlu, a.n_accepted, a.n_rejected) == (b.status, b.nfev, b.njev, b.nlu, b.n_accepted, b.n_rejected)
+    assert np.array_equal(a.y_final, b.y_final)
+    assert all(np.array_equal(x, y) for x, y in zip(a.t_events, b.t_events))
+    y, st, *_ = oracle.radau(oracle.params_from_dict(p | {"dPhi_variable": 1}), N, y0, 0.0, 0.5, 1e-6, 1e-3, 1e-3)
+    assert st.status == b.status == 0
+    assert abs(b.nfev - st.nfev) <= max(6, 0.03 * st.nfev) and abs(b.n_accepted - st.n_accepted) <= 2
+    assert np.max(np.abs(b.y_final - y)) < 2e-3
