@@ -72,6 +72,8 @@ int marl_synchronize(marl_ctx* ctx);
  *   one workgroup; 0: one RHS launch, one linear-algebra launch and one wait per Newton iteration - bit-identical),
  *   rk4_stream (fixed-step RK4 of one grid as ONE dataflow launch over (level, tile) work items instead of one launch per
  *   fused level: 0 never, 1 - the default - for grids of 196 608 cells or more, 2 always; results are bit-identical),
+ *   rk4_stream_third (1, the default: a streamed call with an odd number of levels runs through a third state buffer instead of
+ *   copying the state back afterwards; 0: copy - bit-identical),
  *   rk4_stream_test_raise (test hook: the next streamed run starts with its give-up flag raised - marl_synchronize must
  *   report error -2 and the context must recover), rk4_stream_max_items (test hook: work items per streamed launch, default
  *   2^31 - 1: a call with more (level, tile) items is split into several launches of an even number of levels). */

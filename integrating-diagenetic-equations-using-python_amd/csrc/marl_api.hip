@@ -82,6 +82,9 @@ struct marl_ctx {
     // options
     int64_t rk4_variant = -1, rk45_variant = -1, sweep_variant = -1, host_layout = LAYOUT_TILED, poll = 64;
     int64_t rk4_stream = 1;     // the fixed-step loop of one grid as ONE dataflow launch (rk4_stream_kernel): 0 never, 1 large grids, 2 always
+    int64_t rk4_stream_third = 1;   // an odd number of levels goes through a third state buffer, so that no whole-state copy follows (0: copy)
+    double* stream_c = nullptr;
+    size_t stream_c_cap = 0;
     int64_t implicit_zero_copy = 1;  // scalar results of the implicit drivers through polled host memory (0: copy + synchronise)
     int64_t radau_fused_solve = 3;   // small systems (5 N <= 2048): >= 1: all levels of a solve in one launch (BDF: the whole Newton iteration / solve_bdf_system); Radau single runs: 3 (default) = two launches per Newton iteration (solves with their own right-hand sides | update + norm + the next stage derivatives), 2 = the whole iteration's linear algebra in ONE workgroup (bit-identical, measured slower: the two chains then share one compute unit), 1 = four launches; 0: one launch per level
     int64_t radau_solver = 0;   // 0: block parallel cyclic reduction (parallel over depth); 1: sequential block Thomas
@@ -273,6 +276,7 @@ void marl_ctx_destroy(marl_ctx* ctx)
     for (int i = 0; i < 4; i++)
         if (ctx->buf[i]) (void)hipFree(ctx->buf[i]);
     if (ctx->part) (void)hipFree(ctx->part);
+    if (ctx->stream_c) (void)hipFree(ctx->stream_c);
     if (ctx->sq) (void)hipFree(ctx->sq);
     if (ctx->sq_sticky) (void)hipFree(ctx->sq_sticky);
     if (ctx->sq_host) (void)hipHostFree(ctx->sq_host);
@@ -346,6 +350,7 @@ int marl_set_option(marl_ctx* ctx, const char* name, int64_t value)
     else if (n == "radau_sweep_wg") ctx->radau_sweep_wg = value < 0 ? 0 : (value > 3 ? 3 : value);
     else if (n == "implicit_zero_copy") ctx->implicit_zero_copy = value ? 1 : 0;
     else if (n == "rk4_stream") ctx->rk4_stream = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (n == "rk4_stream_third") ctx->rk4_stream_third = value ? 1 : 0;
     else if (n == "rk4_stream_test_raise") ctx->sq_test_raise = value != 0;
     else if (n == "rk4_stream_max_items") ctx->sq_max_items = value > 0 ? std::min<int64_t>(value, 0x7fffffff) : 0x7fffffff;
     else if (n == "no_reuse") {
@@ -497,17 +502,18 @@ static int default_rk4_variant(const marl_ctx* ctx)
 
 // One dataflow launch for `levels` x `per` steps (rk4_stream_kernel): bufA -> ... -> (levels odd ? bufB : bufA)
 template <int NSTEPS, bool VD = false>
-static void launch_stream_t(marl_ctx* ctx, double* a, double* b, int layout, double dt, unsigned levels, unsigned tiles, unsigned blocks)
+static void launch_stream_t(marl_ctx* ctx, double* a, double* b, int layout, double dt, unsigned levels, unsigned tiles, unsigned blocks, double* c = nullptr)
 {
     if (layout == LAYOUT_TILED)
         hipLaunchKernelGGL((rk4_stream_kernel<256, LAYOUT_TILED, NSTEPS, VD>), dim3(blocks), dim3(256), 0, ctx->stream, a, b, ctx->dconsts, ctx->slab, dt,
-                           levels, tiles, ctx->sq, ctx->sq + 2, ctx->sq_sticky, ctx->sq_item_base, ctx->sq_level_base);
+                           levels, tiles, ctx->sq, ctx->sq + 2, ctx->sq_sticky, ctx->sq_item_base, ctx->sq_level_base, c);
     else
         hipLaunchKernelGGL((rk4_stream_kernel<256, LAYOUT_FIELD_MAJOR, NSTEPS, VD>), dim3(blocks), dim3(256), 0, ctx->stream, a, b, ctx->dconsts, ctx->slab,
-                           dt, levels, tiles, ctx->sq, ctx->sq + 2, ctx->sq_sticky, ctx->sq_item_base, ctx->sq_level_base);
+                           dt, levels, tiles, ctx->sq, ctx->sq + 2, ctx->sq_sticky, ctx->sq_item_base, ctx->sq_level_base, c);
 }
 
-static int rk4_stream(marl_ctx* ctx, double* a, double* b, int layout, double dt, int per, int64_t levels)
+// *result: where the state is afterwards (a or b)
+static int rk4_stream(marl_ctx* ctx, double* a, double* b, int layout, double dt, int per, int64_t levels, double** result)
 {
     const int64_t n = ctx->slab.out_hi - ctx->slab.out_lo, V = 256 - 8 * per, tiles = (n + V - 1) / V;
     if (!ctx->cus) {
@@ -540,16 +546,29 @@ static int rk4_stream(marl_ctx* ctx, double* a, double* b, int layout, double dt
         const int64_t cap = (ctx->sq_max_items / tiles) & ~(int64_t)1;
         const int64_t lv = std::min<int64_t>(levels, std::max<int64_t>(cap, 2));
         const unsigned blocks = (unsigned)std::min<int64_t>(lv * tiles, 4 * (int64_t)ctx->cus);   // 4 workgroups of 256 per CU are resident
+        // the LAST launch with an odd number (>= 3) of levels goes A -> B, B <-> C, ... -> A through a third buffer: the result lands where
+        // the caller's state is and the whole-state copy afterwards goes away (12 us of a 20-step call at N = 2^20; option rk4_stream_third)
+        double* c = nullptr;
+        if (ctx->rk4_stream_third && levels == lv && (lv & 1) && lv >= 3) {
+            const size_t need = (size_t)state_doubles(ctx->slab.n_buf, layout);
+            if (ctx->stream_c_cap < need) {
+                if (ctx->stream_c) HIP_OK(ctx, hipFree(ctx->stream_c));
+                ctx->stream_c = nullptr; ctx->stream_c_cap = 0;
+                HIP_OK(ctx, hipMalloc((void**)&ctx->stream_c, need * sizeof(double)));
+                ctx->stream_c_cap = need;
+            }
+            c = ctx->stream_c;
+        }
         switch (per) {
-            case 1: if (ctx->var_dphi) launch_stream_t<1, true>(ctx, a, b, layout, dt, (unsigned)lv, (unsigned)tiles, blocks);
-                    else launch_stream_t<1>(ctx, a, b, layout, dt, (unsigned)lv, (unsigned)tiles, blocks);
+            case 1: if (ctx->var_dphi) launch_stream_t<1, true>(ctx, a, b, layout, dt, (unsigned)lv, (unsigned)tiles, blocks, c);
+                    else launch_stream_t<1>(ctx, a, b, layout, dt, (unsigned)lv, (unsigned)tiles, blocks, c);
                     break;
-            case 2: launch_stream_t<2>(ctx, a, b, layout, dt, (unsigned)lv, (unsigned)tiles, blocks); break;
-            case 4: if (ctx->var_dphi) launch_stream_t<4, true>(ctx, a, b, layout, dt, (unsigned)lv, (unsigned)tiles, blocks);
-                    else launch_stream_t<4>(ctx, a, b, layout, dt, (unsigned)lv, (unsigned)tiles, blocks);
+            case 2: launch_stream_t<2>(ctx, a, b, layout, dt, (unsigned)lv, (unsigned)tiles, blocks, c); break;
+            case 4: if (ctx->var_dphi) launch_stream_t<4, true>(ctx, a, b, layout, dt, (unsigned)lv, (unsigned)tiles, blocks, c);
+                    else launch_stream_t<4>(ctx, a, b, layout, dt, (unsigned)lv, (unsigned)tiles, blocks, c);
                     break;
-            case 8: launch_stream_t<8>(ctx, a, b, layout, dt, (unsigned)lv, (unsigned)tiles, blocks); break;
-            case 16: launch_stream_t<16>(ctx, a, b, layout, dt, (unsigned)lv, (unsigned)tiles, blocks); break;
+            case 8: launch_stream_t<8>(ctx, a, b, layout, dt, (unsigned)lv, (unsigned)tiles, blocks, c); break;
+            case 16: launch_stream_t<16>(ctx, a, b, layout, dt, (unsigned)lv, (unsigned)tiles, blocks, c); break;
             default: return fail(ctx, -1, "rk4 stream: %d steps per level not instantiated", per);
         }
         LAUNCH_OK(ctx);
@@ -557,8 +576,9 @@ static int rk4_stream(marl_ctx* ctx, double* a, double* b, int layout, double dt
         ctx->sq_item_base += (unsigned)(lv * tiles) + blocks;   // its items + one failing grab per workgroup (wraps with the counter)
         ctx->sq_level_base += (unsigned)lv;
         levels -= lv;
-        if (levels > 0 && (lv & 1)) std::swap(a, b);
+        if ((lv & 1) && !c) std::swap(a, b);   // (now `a` holds the state)
     }
+    *result = a;
     return 0;
 }
 
@@ -578,8 +598,9 @@ static int rk4_run(marl_ctx* ctx, double* y, double* tmp, int layout, double dt,
                                              : (ctx->rk4_stream == 1 && ctx->slab.out_hi - ctx->slab.out_lo >= kStreamMinCells && left >= 2 * per);
     if (stream && ctx->halo == 0) {
         const int64_t levels = left / per;
-        if (int rc = rk4_stream(ctx, a, b, layout, dt, per, levels)) return rc;
-        if (levels & 1) std::swap(a, b);
+        double* now = nullptr;
+        if (int rc = rk4_stream(ctx, a, b, layout, dt, per, levels, &now)) return rc;
+        if (now != a) std::swap(a, b);
         left -= levels * per;
     }
     while (left >= per) {

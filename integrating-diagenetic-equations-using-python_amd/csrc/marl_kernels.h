@@ -582,8 +582,12 @@ constexpr unsigned STREAM_SPIN_LIMIT = 1u << 19;
 template <int BLK, int LAYOUT, int NSTEPS, bool VD = false>
 __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8)))
 rk4_stream_kernel(double* bufA, double* bufB, const DevConsts* __restrict__ consts, Slab S, double dt, unsigned levels, unsigned tiles,
-                  unsigned* queue, unsigned* done, unsigned* sticky, unsigned item_base, unsigned level_base)
+                  unsigned* queue, unsigned* done, unsigned* sticky, unsigned item_base, unsigned level_base, double* bufC = nullptr)
 {
+    // bufC != NULL (an ODD number of levels >= 3 in this launch): A -> B, then B <-> C, the last level back into A - the result lands in the
+    // caller's buffer and the whole-state copy that an odd level count used to need afterwards (42 MB at N = 2^20: 12 us of a 20-step
+    // call) goes away.  The write-after-read distance is that of the two-buffer scheme (a level writes what the level before reads, and
+    // done[tile +- 1] orders it); the last level writes A, which only level 0 reads - five or more tiles of dependency away.
     constexpr int CPT = 1;
     constexpr int H = 4 * NSTEPS;
     constexpr int V = BLK - 2 * H;
@@ -638,8 +642,8 @@ rk4_stream_kernel(double* bufA, double* bufB, const DevConsts* __restrict__ cons
             __syncthreads();
             if (s_abort) break;
         }
-        const double* src = (level & 1u) ? bufB : bufA;
-        double* dst = (level & 1u) ? bufA : bufB;
+        const double* src = bufC ? (level == 0 ? bufA : ((level & 1u) ? bufB : bufC)) : ((level & 1u) ? bufB : bufA);
+        double* dst = bufC ? (level + 1 == levels ? bufA : ((level & 1u) ? bufC : bufB)) : ((level & 1u) ? bufA : bufB);
         const int64_t l = S.out_lo + (int64_t)tile * V - H + threadIdx.x;
         const bool in = l >= 0 && l < S.n_buf;
         double y[CPT][NF];

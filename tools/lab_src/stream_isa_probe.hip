@@ -5,7 +5,7 @@
 
 namespace marl {
 template __global__ void rk4_stream_kernel<256, LAYOUT_TILED, 4, false>(double*, double*, const DevConsts*, Slab, double, unsigned, unsigned, unsigned*,
-                                                                        unsigned*, unsigned*, unsigned, unsigned);
+                                                                        unsigned*, unsigned*, unsigned, unsigned, double*);
 template __global__ void rk4_stream_kernel<256, LAYOUT_TILED, 1, false>(double*, double*, const DevConsts*, Slab, double, unsigned, unsigned, unsigned*,
-                                                                        unsigned*, unsigned*, unsigned, unsigned);
+                                                                        unsigned*, unsigned*, unsigned, unsigned, double*);
 }  // namespace marl
