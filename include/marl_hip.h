@@ -41,6 +41,10 @@ typedef struct marl_ctx marl_ctx;
  * (a parameter sweep: one block per instance; the reference runs one instance per process).
  * All instances share N. */
 int marl_ctx_create(const marl_params* params, int64_t n_instances, int64_t N, int device, marl_ctx** out);
+/* New parameters for an existing context (same N, same number of instances): what constructing the reference's model again with other
+ * arguments does (marlpde/LHeureux_model.py:12-133), without giving up the buffers the context has allocated - a loop over scenarios
+ * (the reference's tests, marlpde_amd.sweep.run_sweep_bdf) pays for its allocations once. */
+int marl_ctx_set_params(marl_ctx* ctx, const marl_params* params, int64_t n_instances);
 
 void marl_ctx_destroy(marl_ctx* ctx);
 const char* marl_last_error(const marl_ctx* ctx); /* ctx may be NULL: error of the last failed create */

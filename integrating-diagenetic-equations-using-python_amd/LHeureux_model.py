@@ -107,15 +107,7 @@ class LMAHeureuxPorosityDiff:
         self.device = int(device)
         self._lib = _abi.load()
         self._ctx = C.c_void_p()
-        blocks = (MarlParams * len(self.instances))()
-        for blk, inst in zip(blocks, self.instances):
-            for name in _abi.PARAM_DOUBLES[:30]:
-                setattr(blk, name, float(inst[name]))
-            blk.length = float(Depths.length)
-            blk.shallow_limit = float(inst["ShallowLimit"]) / float(inst["Xstar"])
-            blk.deep_limit = float(inst["DeepLimit"]) / float(inst["Xstar"])
-            blk.FV_switch = int(inst["FV_switch"])
-            blk.dPhi_variable = int(bool(inst.get("dPhi_variable", False)))
+        blocks = self._pack_blocks()
         rc = self._lib.marl_ctx_create(blocks, len(self.instances), N, self.device, C.byref(self._ctx))
         if rc != 0:
             self._ctx = C.c_void_p()
@@ -130,6 +122,45 @@ class LMAHeureuxPorosityDiff:
         x = Depths.axes_coords[0]
         self.not_too_shallow = np.heaviside(x - ShallowLimit / Xstar, 0)
         self.not_too_deep = np.heaviside(DeepLimit / Xstar - x, 0)
+
+    def _pack_blocks(self):
+        blocks = (MarlParams * len(self.instances))()
+        for blk, inst in zip(blocks, self.instances):
+            for name in _abi.PARAM_DOUBLES[:30]:
+                setattr(blk, name, float(inst[name]))
+            blk.length = float(self.Depths.length)
+            blk.shallow_limit = float(inst["ShallowLimit"]) / float(inst["Xstar"])
+            blk.deep_limit = float(inst["DeepLimit"]) / float(inst["Xstar"])
+            blk.FV_switch = int(inst["FV_switch"])
+            blk.dPhi_variable = int(bool(inst.get("dPhi_variable", False)))
+        return blocks
+
+    def set_scenario(self, pde_parms):
+        """The parameters of another scenario (``asdict(Map_Scenario())``-style dict, same N and max_depth / Xstar) for this
+        single-instance model: what constructing the reference's model again does, with the device buffers kept (marl_ctx_set_params)."""
+        import inspect
+        if len(self.instances) != 1:
+            raise ValueError("set_scenario: single-instance models only")
+        names = {p for p in inspect.signature(type(self).__init__).parameters} - {"self", "Depths", "device", "slices_all_fields", "not_too_shallow",
+                                                                                   "not_too_deep", "_extra_instances"}
+        new = {k: v for k, v in pde_parms.items() if k in names}
+        if int(pde_parms.get("N", self.Depths.N)) != self.Depths.N:
+            raise ValueError("set_scenario: the grid size cannot change")
+        inst = dict(self.instances[0]) | new
+        inst["dPhi_variable"] = bool(inst.get("dPhi_variable", False))
+        self.instances = [inst]
+        for k, v in inst.items():
+            setattr(self, k, v)
+        self._check(self._lib.marl_ctx_set_params(self._ctx, self._pack_blocks(), 1), "marl_ctx_set_params")
+        names19 = ("delta_x", "nu1", "nu2", "KRat", "dCa", "dCO3", "delta", "Da", "lambda_", "auxcon", "rhorat0",
+                   "rhorat", "presum", "F_fixed", "dPhi_fixed", "Peclet_min", "Peclet_max", "mask_lo", "mask_hi")
+        vals = (C.c_double * 19)()
+        self._check(self._lib.marl_get_constants(self._ctx, 0, vals), "marl_get_constants")
+        for n_, v in zip(names19, vals):
+            setattr(self, n_, int(v) if n_.startswith("mask_") else float(v))
+        x = self.Depths.axes_coords[0]
+        self.not_too_shallow = np.heaviside(x - inst["ShallowLimit"] / inst["Xstar"], 0)
+        self.not_too_deep = np.heaviside(inst["DeepLimit"] / inst["Xstar"] - x, 0)
 
     # -- construction helpers ------------------------------------------------------------------
     @classmethod

@@ -47,6 +47,7 @@ _I = C.c_int
 _L = C.c_int64
 PROTOTYPES = {
     "marl_ctx_create": (_I, [C.POINTER(MarlParams), _L, _L, _I, C.POINTER(_P)]),
+    "marl_ctx_set_params": (_I, [_P, C.POINTER(MarlParams), _L]),
     "marl_ctx_destroy": (None, [_P]),
     "marl_last_error": (C.c_char_p, [_P]),
     "marl_set_stream": (_I, [_P, _P]),

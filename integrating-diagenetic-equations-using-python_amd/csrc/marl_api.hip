@@ -268,6 +268,28 @@ int marl_ctx_create(const marl_params* params, int64_t n_instances, int64_t N, i
     return 0;
 }
 
+// New parameters for an existing context (same N, same number of instances): the derived constants are recomputed and uploaded; every
+// buffer the context has grown stays (a loop over scenarios pays for its allocations once).  The time-varying dPhi switch may change.
+int marl_ctx_set_params(marl_ctx* ctx, const marl_params* params, int64_t n_instances)
+{
+    if (!ctx || !params) return ctx ? fail(ctx, -1, "marl_ctx_set_params: invalid argument") : -1;
+    if (n_instances != ctx->batch) return fail(ctx, -1, "marl_ctx_set_params: the context holds %lld instance(s)", (long long)ctx->batch);
+    if (ctx->halo > 0) return fail(ctx, -1, "marl_ctx_set_params: not for slab contexts");
+    for (int64_t b = 0; b < n_instances; b++) {
+        if (!(params[b].length > 0)) return fail(ctx, -1, "marl_ctx_set_params: instance %lld: length must be > 0", (long long)b);
+        if ((params[b].dPhi_variable != 0) != (params[0].dPhi_variable != 0))
+            return fail(ctx, -1, "marl_ctx_set_params: dPhi_variable must be the same for every instance of a sweep");
+    }
+    HIP_OK(ctx, hipSetDevice(ctx->device));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));   // nothing in flight reads the old constants
+    ctx->params.assign(params, params + n_instances);
+    for (int64_t b = 0; b < n_instances; b++) derive_consts(params[b], ctx->N, ctx->hconsts[b], &ctx->extra[4 * b]);
+    ctx->var_dphi = params[0].dPhi_variable != 0;
+    HIP_OK(ctx, hipMemcpyAsync(ctx->dconsts, ctx->hconsts.data(), sizeof(DevConsts) * n_instances, hipMemcpyHostToDevice, ctx->stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 void marl_ctx_destroy(marl_ctx* ctx)
 {
     if (!ctx) return;

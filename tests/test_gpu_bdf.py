@@ -205,3 +205,36 @@ def test_bdf_cyclic_reduction_front_end_at_2048_cells():
     assert (b.nfev, b.njev, b.nlu, b.n_accepted) == (c.nfev, c.njev, c.nlu, c.n_accepted) and np.array_equal(b.y_final, c.y_final)
     assert abs(a.nfev - b.nfev) <= max(6, 0.03 * a.nfev) and abs(a.n_accepted - b.n_accepted) <= 3
     assert np.max(np.abs(a.y_final - b.y_final)) < 1e-3
+
+
+def test_run_sweep_bdf_driver_equals_single_runs():
+    """marlpde_amd.sweep.run_sweep_bdf: a shard's instances as concurrent single BDF runs (one context and stream per worker thread):
+    every instance bit for bit its single run, whatever the number of workers."""
+    import time
+    from dataclasses import asdict
+    from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
+    from marlpde_amd.parameters import Map_Scenario
+    from marlpde_amd.sweep import HipSweepEngine, initial_states, product_grid, run_sweep_bdf
+    N = 200
+    base = asdict(Map_Scenario()) | {"N": N}
+    insts = product_grid(Phi0=[0.55, 0.6, 0.65], k3=[0.02, 0.05, 0.08])
+    for d in insts:
+        d.update(PhiIni=d["Phi0"], PhiNR=d["Phi0"], k4=d["k3"])
+    y0 = initial_states(base, insts)
+    t0 = time.time()
+    y, status, acc, rej, t = run_sweep_bdf(base, insts, (0.0, 0.5), 1e-6, 1e-3, 1e-3, device=0)
+    t_sweep = time.time() - t0
+    ref = []
+    t0 = time.time()
+    for b, d in enumerate(insts):
+        one = LMAHeureuxPorosityDiff.from_scenario(base | d, device=0)
+        ref.append(one.integrate_bdf(y0[b], (0.0, 0.5), 1e-6, 1e-3, 1e-3))
+        one.close()
+    t_serial = time.time() - t0
+    print(f"9 instances: threaded sweep {t_sweep:.3f} s, one after another {t_serial:.3f} s")
+    assert list(status) == [r.status for r in ref] and list(acc) == [r.n_accepted for r in ref] and list(rej) == [r.n_rejected for r in ref]
+    assert np.array_equal(y, np.stack([r.y_final for r in ref]))
+    eng = HipSweepEngine(base, insts, 0)
+    y1, res1 = eng.integrate_bdf(y0, (0.0, 0.5), 1e-6, 1e-3, 1e-3, 0, workers=1)
+    eng.close()
+    assert np.array_equal(y1, y) and [r.nfev for r in res1] == [r.nfev for r in ref]
