@@ -146,7 +146,12 @@ class LMAHeureuxPorosityDiff:
         new = {k: v for k, v in pde_parms.items() if k in names}
         if int(pde_parms.get("N", self.Depths.N)) != self.Depths.N:
             raise ValueError("set_scenario: the grid size cannot change")
-        inst = dict(self.instances[0]) | new
+        sig = inspect.signature(type(self).__init__).parameters
+        defaults = {k: sig[k].default for k in names if sig[k].default is not inspect.Parameter.empty}   # as a fresh construction would take them
+        missing = [k for k in names if k not in new and k not in defaults]
+        if missing:
+            raise TypeError(f"set_scenario: missing parameters {sorted(missing)}")
+        inst = defaults | new
         inst["dPhi_variable"] = bool(inst.get("dPhi_variable", False))
         self.instances = [inst]
         for k, v in inst.items():

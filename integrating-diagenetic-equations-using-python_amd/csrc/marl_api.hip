@@ -283,7 +283,11 @@ int marl_ctx_set_params(marl_ctx* ctx, const marl_params* params, int64_t n_inst
     HIP_OK(ctx, hipSetDevice(ctx->device));
     HIP_OK(ctx, hipStreamSynchronize(ctx->stream));   // nothing in flight reads the old constants
     ctx->params.assign(params, params + n_instances);
-    for (int64_t b = 0; b < n_instances; b++) derive_consts(params[b], ctx->N, ctx->hconsts[b], &ctx->extra[4 * b]);
+    const int no_reuse = ctx->hconsts[0].hot.no_reuse;   // (an option of the context, kept)
+    for (int64_t b = 0; b < n_instances; b++) {
+        derive_consts(params[b], ctx->N, ctx->hconsts[b], &ctx->extra[4 * b]);
+        ctx->hconsts[b].hot.no_reuse = no_reuse;
+    }
     ctx->var_dphi = params[0].dPhi_variable != 0;
     HIP_OK(ctx, hipMemcpyAsync(ctx->dconsts, ctx->hconsts.data(), sizeof(DevConsts) * n_instances, hipMemcpyHostToDevice, ctx->stream));
     HIP_OK(ctx, hipStreamSynchronize(ctx->stream));

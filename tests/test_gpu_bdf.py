@@ -238,3 +238,27 @@ def test_run_sweep_bdf_driver_equals_single_runs():
     y1, res1 = eng.integrate_bdf(y0, (0.0, 0.5), 1e-6, 1e-3, 1e-3, 0, workers=1)
     eng.close()
     assert np.array_equal(y1, y) and [r.nfev for r in res1] == [r.nfev for r in ref]
+
+
+def test_set_scenario_equals_a_fresh_model():
+    """marl_ctx_set_params / LMAHeureuxPorosityDiff.set_scenario: after taking another scenario's parameters an existing model gives the
+    bits a freshly constructed one gives - derived constants, RHS, an RK45 run and a Radau run - also when the dPhi switch changes."""
+    from common import scenario
+    from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
+    N = 200
+    pa, pb = scenario("A", N), scenario("matlab", N) | {"dPhi_variable": True}
+    rng = np.random.default_rng(3)
+    eq = LMAHeureuxPorosityDiff.from_scenario(pa, device=0)
+    for p in (pb, pa):
+        eq.set_scenario(p)
+        fresh = LMAHeureuxPorosityDiff.from_scenario(p, device=0)
+        y0 = np.concatenate([np.full(N, p[k]) for k in ("CAIni", "CCIni", "cCaIni", "cCO3Ini", "PhiIni")]) * (1 + 0.01 * rng.standard_normal(5 * N))
+        for name in ("Da", "presum", "rhorat", "dPhi_fixed", "mask_lo", "mask_hi"):
+            assert getattr(eq, name) == getattr(fresh, name)
+        assert np.array_equal(eq.fun(0.0, y0), fresh.fun(0.0, y0))
+        a, b = eq.integrate_rk45(y0, (0.0, 2e-4), 1e-6, 1e-3, 1e-3), fresh.integrate_rk45(y0, (0.0, 2e-4), 1e-6, 1e-3, 1e-3)
+        assert (a.n_accepted, a.n_rejected) == (b.n_accepted, b.n_rejected) and np.array_equal(a.y[:, -1], b.y[:, -1])
+        a, b = eq.integrate_radau(y0, (0.0, 0.05), 1e-6, 1e-3, 1e-3), fresh.integrate_radau(y0, (0.0, 0.05), 1e-6, 1e-3, 1e-3)
+        assert (a.nfev, a.njev, a.nlu) == (b.nfev, b.njev, b.nlu) and np.array_equal(a.y_final, b.y_final)
+        fresh.close()
+    eq.close()
