@@ -123,6 +123,7 @@ def main():
     import torch
     import torch.distributed as dist
     from dataclasses import asdict
+    from marlpde_amd import _abi
     from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
     from marlpde_amd.parameters import Map_Scenario
 
@@ -433,6 +434,10 @@ def main():
                        "parallelism": parallelism,
                        "timing": f"median of {reps} block(s) of {steps} steps, each bracketed by barrier + synchronize; max over ranks per block"},
             "roofline": roof, "cpu_baseline": cpu,
+            # which build of the library produced this line (MARL_HIP_LIBRARY / MARL_HIP_OPTIONS are kernel-lab overrides: a line
+            # taken with either set says so)
+            "library": dict(zip(("path", "sha256_16"), _abi.library_fingerprint())) | {
+                "overridden": bool(os.environ.get("MARL_HIP_LIBRARY")), "lab_options": os.environ.get("MARL_HIP_OPTIONS", "")},
         }
 
     # ---- extras: the other BASELINE configs, best effort under a deadline -----------------------------------

@@ -112,6 +112,8 @@ class LMAHeureuxPorosityDiff:
         if rc != 0:
             self._ctx = C.c_void_p()
             _abi.check(None, rc, "marl_ctx_create")
+        for name, value in _abi.lab_options():   # (kernel-lab A/B runs only: MARL_HIP_OPTIONS="name=value,..."; bench.py records it)
+            self.set_option(name, value)
         # derived constants, named as in the reference (:36-72, :130-133)
         names = ("delta_x", "nu1", "nu2", "KRat", "dCa", "dCO3", "delta", "Da", "lambda_", "auxcon", "rhorat0",
                  "rhorat", "presum", "F_fixed", "dPhi_fixed", "Peclet_min", "Peclet_max", "mask_lo", "mask_hi")
@@ -146,6 +148,13 @@ class LMAHeureuxPorosityDiff:
         new = {k: v for k, v in pde_parms.items() if k in names}
         if int(pde_parms.get("N", self.Depths.N)) != self.Depths.N:
             raise ValueError("set_scenario: the grid size cannot change")
+        # the column's length max_depth / Xstar (Evolve_scenario.py:27-31) may change with the scenario: the grid - and with it delta_x,
+        # the masks and the cell centres - is rebuilt, exactly as constructing the model again would (marl_ctx_set_params re-derives
+        # every constant from the new length)
+        if "max_depth" in pde_parms and "Xstar" in pde_parms:
+            length = float(pde_parms["max_depth"]) / float(pde_parms["Xstar"])
+            if length != self.Depths.length:
+                self.Depths = DepthGrid(length, self.Depths.N)
         sig = inspect.signature(type(self).__init__).parameters
         defaults = {k: sig[k].default for k in names if sig[k].default is not inspect.Parameter.empty}   # as a fresh construction would take them
         missing = [k for k in names if k not in new and k not in defaults]

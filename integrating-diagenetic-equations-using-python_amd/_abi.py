@@ -11,6 +11,26 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # (MARL_HIP_LIBRARY: another BUILD of the same library - kernel-lab A/B runs on the GPU box; never a different implementation)
 LIB_PATH = os.environ.get("MARL_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "libmarl_hip.so")
 
+
+
+def lab_options():
+    """[(name, value)] from MARL_HIP_OPTIONS="name=value,..." - library options (marl_set_option) applied to every context the
+    Python layer creates.  For kernel-lab A/B runs on one box; bench.py records the variable in its output line."""
+    out = []
+    for item in os.environ.get("MARL_HIP_OPTIONS", "").split(","):
+        if item.strip():
+            name, _, value = item.partition("=")
+            out.append((name.strip(), int(value)))
+    return out
+
+
+def library_fingerprint():
+    """(path, first 16 hex digits of the sha256) of the library in use."""
+    import hashlib
+    with open(LIB_PATH, "rb") as f:
+        return LIB_PATH, hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 NFIELDS = 5
 NEVENTS = 7
 LAYOUT_FIELD_MAJOR = 0

@@ -53,6 +53,16 @@ struct marl_ctx {
     unsigned* sq_host = nullptr;   // pinned: copy of sq_sticky
     bool sq_pending = false;       // streamed runs since sq_sticky was last looked at
     int cus = 0;
+    // persistent adaptive loop (rk45_stream_kernel): barrier / publication words, one record per resident workgroup; the ticket and
+    // barrier counters are never reset between launches - rs_arrive_base / rs_epoch_base say where they stand
+    Rk45Stream* rs = nullptr;
+    double* rs_grec = nullptr;
+    unsigned* rs_host = nullptr;   // pinned: copy of {arrive, sticky}
+    unsigned rs_arrive_base = 0, rs_epoch_base = 0, rs_grab_base = 0, rs_G = 0, rs_grabs_per_attempt = 0;
+    int rs_occ[2][2] = {{0, 0}, {0, 0}};   // resident workgroups per CU of the instantiation [tiled][VD]
+    int64_t rk45_stream = 1;       // the adaptive loop of one grid as ONE launch per batch of attempts (rk45_stream_kernel): 0 never, 1 where it is faster (grids of up to kRk45StreamRounds rounds of resident workgroups), 2 always
+    int64_t dd_stream = 0;         // domain-decomposed loop inside the library: 0 (default) attempt + reduce + pack launches; 1 / 2: the slab's attempt as ONE launch of the persistent kernel whose last workgroup packs the rank's message (1: slabs of up to kRk45StreamRounds rounds, 2: always) - built for the 8-GPU shard size and measured there NOT faster (44.5 us against 34.9 + 4.7 + 4.7 us, profiles/r04_lab_rk45_stream.log)
+    int64_t rk45_stream_attempts = 4096;   // attempts per launch at most (the host looks at the status and the sticky flag in between)
     double* rec = nullptr;  // [batch][NQ]
     Rk45Ctrl* dctrl = nullptr;
     Rk45Ctrl* hctrl = nullptr;  // pinned
@@ -121,6 +131,17 @@ static int fail(marl_ctx* ctx, int code, const char* fmt, ...)
         hipError_t e_ = hipGetLastError();                                                        \
         if (e_ != hipSuccess) return fail(ctx, -100 - (int)e_, "kernel launch failed: %s", hipGetErrorString(e_)); \
     } while (0)
+
+#ifdef MARL_LAB_CLOCK45
+extern "C" int marl_lab_read_clock45(unsigned long long* dst, size_t n)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(marl::marl_lab_clock45), n * sizeof(unsigned long long));
+}
+extern "C" int marl_lab_read_clock45t(unsigned long long* dst, size_t n)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(marl::marl_lab_clock45t), n * sizeof(unsigned long long));
+}
+#endif
 
 // ----------------------------------------------------------------------------------------------
 // Derived constants: LMAHeureuxPorosityDiff.__init__, marlpde/LHeureux_model.py:23-24, :36-72,
@@ -306,6 +327,9 @@ void marl_ctx_destroy(marl_ctx* ctx)
     if (ctx->sq) (void)hipFree(ctx->sq);
     if (ctx->sq_sticky) (void)hipFree(ctx->sq_sticky);
     if (ctx->sq_host) (void)hipHostFree(ctx->sq_host);
+    if (ctx->rs) (void)hipFree(ctx->rs);
+    if (ctx->rs_grec) (void)hipFree(ctx->rs_grec);
+    if (ctx->rs_host) (void)hipHostFree(ctx->rs_host);
     if (ctx->rec) (void)hipFree(ctx->rec);
     if (ctx->dctrl) (void)hipFree(ctx->dctrl);
     if (ctx->ddt) (void)hipFree(ctx->ddt);
@@ -376,6 +400,9 @@ int marl_set_option(marl_ctx* ctx, const char* name, int64_t value)
     else if (n == "radau_sweep_wg") ctx->radau_sweep_wg = value < 0 ? 0 : (value > 3 ? 3 : value);
     else if (n == "implicit_zero_copy") ctx->implicit_zero_copy = value ? 1 : 0;
     else if (n == "rk4_stream") ctx->rk4_stream = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (n == "rk45_stream") ctx->rk45_stream = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (n == "dd_stream") ctx->dd_stream = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (n == "rk45_stream_attempts") ctx->rk45_stream_attempts = value < 1 ? 1 : std::min<int64_t>(value, 1 << 20);
     else if (n == "rk4_stream_third") ctx->rk4_stream_third = value ? 1 : 0;
     else if (n == "rk4_stream_test_raise") ctx->sq_test_raise = value != 0;
     else if (n == "rk4_stream_max_items") ctx->sq_max_items = value > 0 ? std::min<int64_t>(value, 0x7fffffff) : 0x7fffffff;
@@ -694,6 +721,7 @@ static int64_t rk45_blocks(const marl_ctx* ctx, int v)
     return (n + V - 1) / V;
 }
 
+constexpr int64_t kReduceGroups = 64;
 template <int BLK, int CPT, bool VD = false>
 static void launch_attempt_t(marl_ctx* ctx, int64_t nb, int layout)
 {
@@ -707,7 +735,6 @@ static void launch_attempt_t(marl_ctx* ctx, int64_t nb, int layout)
 
 // Records of a large grid are reduced in two levels: `*nrec` per-workgroup records at ctx->part -> at most kReduceGroups
 // records behind them (same buffer, offset `*nrec`); returns where the second level reads and updates *nrec.
-constexpr int64_t kReduceGroups = 64;
 static const double* reduce_first_level(marl_ctx* ctx, int64_t* nrec)
 {
     const int64_t nb = *nrec;
@@ -732,6 +759,103 @@ static int launch_attempt(marl_ctx* ctx, int v, int layout)
     LAUNCH_OK(ctx);
     hipLaunchKernelGGL(rk45_control_kernel, dim3(1), dim3(CONTROL_THREADS), 0, ctx->stream, recs, nrec, ctx->dctrl);
     LAUNCH_OK(ctx);
+    return 0;
+}
+
+// ---- the adaptive loop of one grid as ONE launch per batch of attempts (rk45_stream_kernel) ----------------------------------
+// barrier words zeroed, the grid-wide extrema armed (+inf); synchronises
+static int rk45_stream_reset(marl_ctx* ctx)
+{
+    std::vector<double> inf((size_t)GREC_DOUBLES - MON_OFFSET, (double)INFINITY);
+    HIP_OK(ctx, hipMemsetAsync(ctx->rs, 0, sizeof(Rk45Stream), ctx->stream));
+    HIP_OK(ctx, hipMemsetAsync(ctx->rs_grec, 0, sizeof(double) * MON_OFFSET, ctx->stream));
+    HIP_OK(ctx, hipMemcpyAsync(ctx->rs_grec + MON_OFFSET, inf.data(), inf.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->rs_arrive_base = ctx->rs_epoch_base = ctx->rs_grab_base = 0;
+    return 0;
+}
+
+static int rk45_stream_setup(marl_ctx* ctx)
+{
+    if (!ctx->cus) {
+        hipDeviceProp_t prop;
+        HIP_OK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        ctx->cus = prop.multiProcessorCount;
+    }
+    if (!ctx->rs) {
+        HIP_OK(ctx, hipMalloc((void**)&ctx->rs, sizeof(Rk45Stream)));
+        HIP_OK(ctx, hipMalloc((void**)&ctx->rs_grec, sizeof(double) * GREC_DOUBLES));
+        HIP_OK(ctx, hipHostMalloc((void**)&ctx->rs_host, 2 * sizeof(unsigned), hipHostMallocDefault));
+        if (int rc = rk45_stream_reset(ctx)) return rc;
+    }
+    if (ctx->rs_arrive_base > (1u << 30) || ctx->rs_epoch_base > (1u << 30) || ctx->rs_grab_base > (1u << 30))   // (the stream is idle between batches: the caller has synchronised)
+        if (int rc = rk45_stream_reset(ctx)) return rc;
+    return 0;
+}
+
+// dd: one attempt of a slab; the last workgroup packs the rank's message into ctx->dd_send and re-arms the counters (bases 0)
+template <bool VD>
+static int launch_rk45_stream_t(marl_ctx* ctx, int layout, int64_t tiles, int64_t max_attempts, bool dd = false)
+{
+    auto kern = layout == LAYOUT_TILED ? rk45_stream_kernel<256, LAYOUT_TILED, VD> : rk45_stream_kernel<256, LAYOUT_FIELD_MAJOR, VD>;
+    int& occ = ctx->rs_occ[layout == LAYOUT_TILED ? 1 : 0][VD ? 1 : 0];
+    if (!occ) {
+        HIP_OK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, 0));
+        if (occ < 1) return fail(ctx, -3, "rk45 stream: the kernel does not fit a compute unit");
+        if (occ > 16) occ = 16;
+    }
+    // every workgroup of the grid must be resident at once (they meet at a barrier in memory): at most what the device holds
+    ctx->rs_G = (unsigned)std::min<int64_t>(std::min<int64_t>(tiles, (int64_t)occ * ctx->cus), MON_OFFSET);
+    hipLaunchKernelGGL(kern, dim3(ctx->rs_G), dim3(256), 0, ctx->stream, ctx->buf[0], ctx->buf[1], ctx->buf[2], ctx->buf[3], ctx->dconsts, ctx->slab,
+                       ctx->dctrl, ctx->rs_grec, ctx->rs, (unsigned)tiles, dd ? 0u : ctx->rs_arrive_base, dd ? 0u : ctx->rs_epoch_base, dd ? 0u : ctx->rs_grab_base,
+                       dd ? 1u : (unsigned)max_attempts, dd ? ctx->dd_send : (double*)nullptr, dd ? ctx->halo : 0);
+    const unsigned R = (unsigned)(tiles % ctx->rs_G);
+    ctx->rs_grabs_per_attempt = R ? R + ctx->rs_G : 0;   // (what the kernel's workgroups take from the remainder counter per attempt)
+    LAUNCH_OK(ctx);
+    return 0;
+}
+
+// Where the persistent loop pays (profiles/r04_lab_rk45_stream.log; MI355X, 1024 resident workgroups): what it removes is the fixed
+// cost per attempt - two small launches and every workgroup's prologue, ~8 us against a ~5 us barrier - and what it loses is the
+// dispatcher's balancing: its workgroups own STATIC tiles, the SIMDs arbitrate oldest-first, so a CU's four workgroups finish
+// one after the other and the last runs alone.  N = 65 536: +35 %, 2^19: +7 %, 2^20: -1 %, 2^22: -10 %.  Default: grids of up to
+// three rounds of resident workgroups (N <= ~750 000 cells on 256 CUs); larger grids keep one launch per attempt.
+constexpr int64_t kRk45StreamRounds = 3;
+static bool rk45_use_stream(marl_ctx* ctx, int v)
+{
+    if (ctx->rk45_stream == 0) return false;
+    if (ctx->rk45_stream >= 2) return true;
+    if (!ctx->cus) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return false;
+        ctx->cus = prop.multiProcessorCount;
+    }
+    return rk45_blocks(ctx, v) <= kRk45StreamRounds * 4 * (int64_t)ctx->cus;
+}
+
+static int launch_rk45_stream(marl_ctx* ctx, int v, int layout, int64_t max_attempts, bool dd = false)
+{
+    if (int rc = rk45_stream_setup(ctx)) return rc;
+    const int64_t tiles = rk45_blocks(ctx, v);
+    if (tiles >= (1ll << 31)) return fail(ctx, -1, "rk45 stream: grid too large");
+    return ctx->var_dphi ? launch_rk45_stream_t<true>(ctx, layout, tiles, max_attempts, dd) : launch_rk45_stream_t<false>(ctx, layout, tiles, max_attempts, dd);
+}
+
+// after the batch's status read-back (stream idle): where the ticket / barrier counters stand now, and the sticky flag
+static int rk45_stream_account(marl_ctx* ctx, int64_t attempts_in_batch)
+{
+    HIP_OK(ctx, hipMemcpyAsync(ctx->rs_host, ctx->rs, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    const bool consistent = ctx->rs_host[0] - ctx->rs_arrive_base == ctx->rs_G * (unsigned)attempts_in_batch;
+    if (ctx->rs_host[1] || !consistent) {
+        const unsigned took = ctx->rs_host[0] - ctx->rs_arrive_base;
+        if (int rc = rk45_stream_reset(ctx)) return rc;
+        if (ctx->rs_host[1]) return fail(ctx, -2, "rk45: the persistent time loop gave up waiting at its barrier (rk45_stream_kernel); the state is invalid");
+        return fail(ctx, -2, "rk45: the persistent time loop took %u tickets for %lld attempts of %u workgroups", took, (long long)attempts_in_batch, ctx->rs_G);
+    }
+    ctx->rs_arrive_base += ctx->rs_G * (unsigned)attempts_in_batch;
+    ctx->rs_epoch_base += (unsigned)attempts_in_batch;
+    ctx->rs_grab_base += ctx->rs_grabs_per_attempt * (unsigned)attempts_in_batch;
     return 0;
 }
 
@@ -761,6 +885,7 @@ static const double kDpP[7][4] = {
 // seven monitors into g (may be NULL; synchronises when given).
 static int dense_eval(marl_ctx* ctx, int v, int layout, bool small, const Rk45Ctrl& c, double t, double* yout, double* g)
 {
+
     const double x = (t - c.t_old) / c.h_prev;
     DenseWeights dw;
     double pw[4] = {x, x * x, x * x * x, x * x * x * x};
@@ -884,6 +1009,7 @@ static int rk45_run(marl_ctx* ctx, int layout, bool small, double t0, double t1,
     int64_t seen_events[7] = {0, 0, 0, 0, 0, 0, 0};
     Rk45Ctrl& hc = *ctx->hctrl;
     int64_t executed = 0;   // attempts the device has finished, as of the last status read
+    const bool streamed = !small && rk45_use_stream(ctx, v);   // one launch per batch of attempts (rk45_stream_kernel)
     while (true) {
         if (small) {
             const int v = sv;  // SWEEP_DISPATCH switches on `v`
@@ -894,6 +1020,8 @@ static int rk45_run(marl_ctx* ctx, int layout, bool small, double t0, double t1,
                 SWEEP_DISPATCH(rk45_sweep_kernel, ctx->buf[0], ctx->dconsts, ctx->dctrl, ctx->N, ctx->buf[1], ctx->buf[3])
             }
             LAUNCH_OK(ctx);
+        } else if (streamed) {
+            if (int rc = launch_rk45_stream(ctx, v, layout, ctx->rk45_stream_attempts)) return rc;
         } else {
             const int64_t batch = attempts_per_batch(ctx->poll, max_attempts, executed);
             for (int64_t i = 0; i < batch; i++)
@@ -901,7 +1029,10 @@ static int rk45_run(marl_ctx* ctx, int layout, bool small, double t0, double t1,
         }
         HIP_OK(ctx, hipMemcpyAsync(ctx->hctrl, ctx->dctrl, sizeof(Rk45Ctrl), hipMemcpyDeviceToHost, ctx->stream));
         HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+        const int64_t executed_before = executed;
         executed = hc.attempts - (hc.status == ST_RUNNING ? 1 : 0);   // (a running controller has already prepared the next one)
+        if (streamed)
+            if (int rc = rk45_stream_account(ctx, executed - executed_before)) return rc;
         if (hc.status == ST_RUNNING) continue;
         const bool stepped = hc.n_acc > 0;
         // event roots inside the last accepted step (ivp.py:673-694)
@@ -1400,18 +1531,45 @@ int marl_slab_run(marl_ctx* ctx, marl_stats* stats)
     if (int rc = ensure_part(ctx, (size_t)std::max<int64_t>(nb + kReduceGroups, 1024))) return rc;
     const int msg = dd_msg(ctx);
     int64_t executed = 0;
+    if (ctx->dd_world == 1 && !ctx->rccl_comm && rk45_use_stream(ctx, v)) {
+        // ONE slab and no communicator: nothing is exchanged - the single-grid integrator's persistent loop (same kernel, same bits)
+        while (true) {
+            if (int rc = launch_rk45_stream(ctx, v, LAYOUT_FIELD_MAJOR, ctx->rk45_stream_attempts)) return rc;
+            HIP_OK(ctx, hipMemcpyAsync(ctx->hctrl, ctx->dctrl, sizeof(Rk45Ctrl), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+            const int64_t before = executed;
+            executed = ctx->hctrl->attempts - (ctx->hctrl->status == ST_RUNNING ? 1 : 0);
+            if (int rc = rk45_stream_account(ctx, executed - before)) return rc;
+            if (ctx->hctrl->status != ST_RUNNING) break;
+        }
+        ctrl_to_stats(*ctx->hctrl, stats);
+        return 0;
+    }
+    // the slab's attempt as ONE launch (rk45_stream_kernel, one attempt, its last workgroup packs the message): two launches + the
+    // all-gather per attempt instead of four.  A batch of them is enqueued blindly (attempts after the controller has stopped return
+    // at once), so the counters are re-armed by the kernel itself; they must be at zero when the first one starts.
+    const bool dd_stream = ctx->dd_stream == 2 || (ctx->dd_stream == 1 && rk45_use_stream(ctx, v));
+    if (dd_stream) {
+        if (int rc = rk45_stream_setup(ctx)) return rc;
+        if (ctx->rs_arrive_base || ctx->rs_epoch_base || ctx->rs_grab_base)
+            if (int rc = rk45_stream_reset(ctx)) return rc;
+    }
     while (true) {
         // (every rank computes the same batch size: the budget and the status are the same everywhere)
         const int64_t batch = attempts_per_batch(ctx->poll, ctx->dd_max_attempts, executed);
         for (int64_t i = 0; i < batch; i++) {
-            if (ctx->var_dphi) launch_attempt_t<256, 1, true>(ctx, nb, LAYOUT_FIELD_MAJOR); else launch_attempt_t<256, 1>(ctx, nb, LAYOUT_FIELD_MAJOR);
-            LAUNCH_OK(ctx);
-            int64_t nrec = nb;
-            const double* recs = reduce_first_level(ctx, &nrec);
-            LAUNCH_OK(ctx);
-            hipLaunchKernelGGL(slab_reduce_pack_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->buf[0], ctx->buf[1], ctx->buf[2], ctx->buf[3], ctx->dctrl, -1,
-                               ctx->slab, ctx->halo, recs, nrec, ctx->dd_send);
-            LAUNCH_OK(ctx);
+            if (dd_stream) {
+                if (int rc = launch_rk45_stream(ctx, v, LAYOUT_FIELD_MAJOR, 1, true)) return rc;
+            } else {
+                if (ctx->var_dphi) launch_attempt_t<256, 1, true>(ctx, nb, LAYOUT_FIELD_MAJOR); else launch_attempt_t<256, 1>(ctx, nb, LAYOUT_FIELD_MAJOR);
+                LAUNCH_OK(ctx);
+                int64_t nrec = nb;
+                const double* recs = reduce_first_level(ctx, &nrec);
+                LAUNCH_OK(ctx);
+                hipLaunchKernelGGL(slab_reduce_pack_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->buf[0], ctx->buf[1], ctx->buf[2], ctx->buf[3], ctx->dctrl, -1,
+                                   ctx->slab, ctx->halo, recs, nrec, ctx->dd_send);
+                LAUNCH_OK(ctx);
+            }
             const double* gathered;
             if (int rc = dd_allgather(ctx, &gathered)) return rc;
             hipLaunchKernelGGL(slab_unpack_control_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->buf[0], ctx->buf[1], ctx->buf[2], ctx->buf[3], ctx->dctrl,

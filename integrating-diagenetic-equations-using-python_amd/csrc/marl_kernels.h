@@ -99,7 +99,14 @@ struct StencilBlock {
     const DevConsts* C;          // full constant block (cold members are read on rare paths only)
     int tid;
     int parity;
-    unsigned first_mask, last_mask, zone_mask;  // bit c: the thread's c-th cell is global cell 0 / N-1 / in the dissolution zone
+    // the thread's c-th cell is global cell 0 (bit c) / global cell N-1 (bit 8 + c) / in the dissolution zone (bit 16 + c): ONE register
+    // instead of three (it lives across every stage, and the fused integrators sit at their register cap)
+    static_assert(CPT <= 8, "three 8-bit fields");
+    unsigned masks;
+    __device__ __forceinline__ unsigned is_first(int c) const { return (masks >> c) & 1u; }
+    __device__ __forceinline__ unsigned is_last(int c) const { return (masks >> (8 + c)) & 1u; }
+    __device__ __forceinline__ unsigned in_zone(int c) const { return (masks >> (16 + c)) & 1u; }
+    __device__ __forceinline__ unsigned is_edge(int c) const { return (masks >> c) & 0x101u; }   // first or last: non-zero
     PointCache<(CACHE && CACHE_LDS) ? WIN : 0> cache[CACHE ? CPT : 1];  // centre of the transcendental expansions (TR_FILL / TR_REUSE / TR_AUTO)
     bool reuse_live[CPT] = {};   // wave-uniform, per cell: the centre is filled and no evaluation since has fallen out of range
 
@@ -115,17 +122,27 @@ struct StencilBlock {
         }
     }
 
+    // Persistent kernels: the per-thread members again, from an index the caller has made opaque inside its work loop - everything
+    // derived from the thread index is then recomputed per work item (a few instructions) instead of being hoisted out of the loop and
+    // kept in (or spilled from) vector registers across it.
+    __device__ __forceinline__ void rebind(int t)
+    {
+        tid = t;
+        if constexpr (CACHE && CACHE_LDS) {
+#pragma unroll
+            for (int c = 0; c < CPT; c++) cache[c].s = lds + EDGE_DOUBLES + TABLE_DOUBLES + c * BLK + t;
+        }
+    }
+
     // (Re)position the window.
     __device__ __forceinline__ void set_window(int64_t g0)
     {
         const int64_t N = C->N, mlo = C->mask_lo, mhi = C->mask_hi;
-        first_mask = last_mask = zone_mask = 0;
+        masks = 0;
 #pragma unroll
         for (int i = 0; i < CPT; i++) {
             const int64_t g = g0 + i;
-            first_mask |= (g == 0) ? (1u << i) : 0u;
-            last_mask |= (g == N - 1) ? (1u << i) : 0u;
-            zone_mask |= (g >= mlo && g < mhi) ? (1u << i) : 0u;
+            masks |= ((g == 0) ? (1u << i) : 0u) | ((g == N - 1) ? (0x100u << i) : 0u) | ((g >= mlo && g < mhi) ? (0x10000u << i) : 0u);
         }
     }
 
@@ -138,19 +155,19 @@ struct StencilBlock {
     {
         if constexpr (WAVE_TILE) {
             PointLocal pl;
-            point_local<CACHE ? MODE : TR_PLAIN, (CACHE && CACHE_LDS) ? WIN : 0, VD>(ys[0], zone_mask & 1u, K, C, T, pl, aux[0], cache[0], reuse_live[0]);
+            point_local<CACHE ? MODE : TR_PLAIN, (CACHE && CACHE_LDS) ? WIN : 0, VD>(ys[0], in_zone(0), K, C, T, pl, aux[0], cache[0], reuse_live[0]);
             double um[NF], up[NF];
 #pragma unroll
             for (int f = 0; f < NF; f++) um[f] = wave_from_left(ys[0][f]);
             const bool need_right_solids = __builtin_amdgcn_ballot_w64(!pl.upw) != 0;
 #pragma unroll
             for (int f = 0; f < NF; f++) up[f] = (f >= 2 || need_right_solids) ? wave_from_right(ys[0][f]) : 0.0;
-            if (__builtin_amdgcn_ballot_w64((first_mask | last_mask) & 1u) != 0) {   // physical boundaries: two cells of the whole grid
-                if (last_mask & 1u) {
+            if (__builtin_amdgcn_ballot_w64(is_edge(0) != 0) != 0) {   // physical boundaries: two cells of the whole grid
+                if (is_last(0)) {
 #pragma unroll
                     for (int f = 0; f < NF; f++) up[f] = ghost_upper(f, ys[0][f], um[f]);
                 }
-                if (first_mask & 1u) {
+                if (is_first(0)) {
 #pragma unroll
                     for (int f = 0; f < NF; f++) um[f] = ghost_lower(C->bc[f], ys[0][f]);
                 }
@@ -167,7 +184,7 @@ struct StencilBlock {
         PointLocal pl[CPT];
 #pragma unroll
         for (int c = 0; c < CPT; c++) {
-            point_local<CACHE ? MODE : TR_PLAIN, (CACHE && CACHE_LDS) ? WIN : 0, VD>(ys[c], (zone_mask >> c) & 1u, K, C, T, pl[c], aux[c], cache[CACHE ? c : 0], reuse_live[c]);
+            point_local<CACHE ? MODE : TR_PLAIN, (CACHE && CACHE_LDS) ? WIN : 0, VD>(ys[c], in_zone(c), K, C, T, pl[c], aux[c], cache[CACHE ? c : 0], reuse_live[c]);
             // one cell at a time: interleaving the cells' evaluations doubles the live temporaries (spills at CPT >= 2)
 #ifndef MARL_LAB_INTERLEAVE_CELLS   // (kernel-lab switch: let the scheduler interleave the cells of a thread - ILP instead of registers)
             if constexpr (CPT > 1) __builtin_amdgcn_sched_barrier(0);
@@ -194,12 +211,12 @@ struct StencilBlock {
                 up[f] = (c == CPT - 1) ? right[f] : ys[c < CPT - 1 ? c + 1 : c][f];
             }
             // physical boundaries: two cells of the whole grid - a wave-uniform branch, skipped by every other wave
-            if (__builtin_amdgcn_ballot_w64(((first_mask | last_mask) >> c) & 1u) != 0) {
-                if (last_mask & (1u << c)) {
+            if (__builtin_amdgcn_ballot_w64(is_edge(c) != 0) != 0) {
+                if (is_last(c)) {
 #pragma unroll
                     for (int f = 0; f < NF; f++) up[f] = ghost_upper(f, ys[c][f], um[f]);
                 }
-                if (first_mask & (1u << c)) {
+                if (is_first(c)) {
 #pragma unroll
                     for (int f = 0; f < NF; f++) um[f] = ghost_lower(C->bc[f], ys[c][f]);
                 }
@@ -868,6 +885,15 @@ __device__ __forceinline__ void rk45_advance_status(Rk45Ctrl& c, bool accepted, 
     if (c.status == ST_RUNNING) rk45_prepare_attempt(c);
 }
 
+// rk45_advance_status after an ACCEPTED step of a run that does not pause on monitor sign changes (the events are then pure
+// bookkeeping and may follow later)
+__device__ __forceinline__ void rk45_advance_status_no_events(Rk45Ctrl& c)
+{
+    if (c.t - c.t_bound >= 0.0) c.status = ST_DONE;
+    else if (c.t >= c.pause_t) c.status = ST_PAUSED;
+    if (c.status == ST_RUNNING) rk45_prepare_attempt(c);
+}
+
 // rec = {sum (err/scale)^2, monitors of y_new}.
 __device__ __forceinline__ void rk45_finish_attempt(Rk45Ctrl& c, const double (&rec)[NQ], const Tables* T = nullptr)
 {
@@ -1008,6 +1034,48 @@ __device__ __forceinline__ double dp45_err2(double esum, double h, double y, dou
 }
 
 // ---------------------------------------------------------------------------------------------
+// Reduction of a tile's eight quantities over its 256 threads with ONE barrier (round 4; the round-1 block_reduce takes four).
+// Each thread writes its q[j] into column j of an LDS area [8][BLK]; after the barrier HALF-WAVE j (32 lanes) reduces column j:
+// lane i combines rows i, i + 32, ..., i + 224 in that order, then a 5-step butterfly over the 32 lanes - a fixed order.
+// Quantity 0 is a sum (NaN-propagating), 1..NQMIN minima, the rest maxima, carried NEGATED through the columns so that every
+// half-wave but the first runs the same v_min_f64 (finite values: see monitors_accumulate<true>).  Result in lane 0 of half-wave j
+// (threads 0, 32, ..., 224), maxima still negated; other lanes hold garbage.
+// Where the columns live when a Dormand-Prince attempt has just finished (no barrier needed in FRONT of the writes): columns 0..6 =
+// the four cache-slot columns + the three park columns (contiguous; both hold thread-PRIVATE data that the thread has finished
+// with), column 7 = field 0 of the parity-0 edge buffer (last read in the fifth evaluation; every wave has passed the sixth's
+// barrier).  The caller must put a barrier between this function's reads and the next writes to those areas.
+// ---------------------------------------------------------------------------------------------
+template <int BLK>
+__device__ __forceinline__ double* attempt_reduce_column(double* lds, int edge_doubles, int j)
+{
+    return j < 7 ? lds + edge_doubles + TABLE_DOUBLES + j * BLK : lds;
+}
+template <int BLK, class SB>
+__device__ __forceinline__ double tile_reduce_halfwaves(const double (&q)[NQ], double* lds, int tid)
+{
+    static_assert(BLK == 256 && NQ == 8, "eight quantities, eight half-waves");
+    static_assert(PC_LDS_SLOTS >= 4 && SB::CACHE, "columns 0..6 = the cache-slot columns (four at least) + three park columns");
+#pragma unroll
+    for (int j = 0; j < NQ; j++) attempt_reduce_column<BLK>(lds, SB::EDGE_DOUBLES, j)[tid] = (j > NQMIN) ? -q[j] : q[j];
+    __syncthreads();
+    const int j = tid >> 5, i = tid & 31;
+    const bool is_sum = j == 0;
+    const double* col = (j < 7 ? lds + SB::EDGE_DOUBLES + TABLE_DOUBLES + j * BLK : lds) + i;
+    double a = col[0];
+#pragma unroll
+    for (int m = 1; m < BLK / 32; m++) {
+        const double o = col[32 * m];
+        a = is_sum ? a + o : __builtin_fmin(a, o);
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) {
+        const double o = __shfl_xor(a, off, 64);
+        a = is_sum ? a + o : __builtin_fmin(a, o);
+    }
+    return a;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Fused adaptive attempt for ONE large grid (or one slab of a domain-decomposed grid): reads
 // (y, f) from buffer `cur`, writes (y_new, f_new) into the other buffer and one reduction record per
 // block; rk45_control_kernel then accepts (flips `cur`) or rejects.  FSAL: f_new becomes K1.
@@ -1081,10 +1149,391 @@ rk45_attempt_kernel(double* __restrict__ Y0, double* __restrict__ Y1,
             monitors_accumulate<true>(q, yn[c], aux[c].U, aux[c].W);   // (the controller reads the extrema of ACCEPTED attempts only: all finite)
         }
     }
-    block_reduce<BLK, NQ, NQMIN, true>(q, lds);   // the edge-exchange buffers are free now
-    if (threadIdx.x == 0) {
+#ifndef MARL_LAB_ATTEMPT_BLOCK_REDUCE   // (kernel-lab switch: the round-1 four-barrier reduction)
+    if constexpr (BLK == 256 && CPT == 1 && PARK >= 3 && SB::CACHE && PC_LDS_SLOTS >= 4) {
+        // one barrier instead of four: columns in LDS areas this thread / every wave has finished with (tile_reduce_halfwaves)
+        const double r = tile_reduce_halfwaves<BLK, SB>(q, lds, threadIdx.x);
+        if ((threadIdx.x & 31) == 0) {
+            const int j = threadIdx.x >> 5;
+            part[(int64_t)blockIdx.x * NQ + j] = (j > NQMIN) ? -r : r;
+        }
+    } else
+#endif
+    {
+        block_reduce<BLK, NQ, NQMIN, true>(q, lds);   // the edge-exchange buffers are free now
+        if (threadIdx.x == 0) {
 #pragma unroll
-        for (int j = 0; j < NQ; j++) part[(int64_t)blockIdx.x * NQ + j] = q[j];
+            for (int j = 0; j < NQ; j++) part[(int64_t)blockIdx.x * NQ + j] = q[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The whole adaptive loop of ONE large grid in ONE launch (round 4): resident workgroups, one device-wide barrier per attempt.
+//
+// What a launch per attempt costs (rk45_attempt_kernel, N = 2^20: 63 us + two small launches): every workgroup pays a prologue
+// (kernel arguments -> the controller's cur / h -> the state loads that depend on cur -> tables into LDS -> barrier), a four-barrier
+// block reduction, and the dispatcher's turnover of its slot; 4 297 tiles on 1 024 slots leave a fifth, 20 % filled round.  Here a
+// grid of G resident workgroups (4 per CU) stages the tables once, keeps (h, cur, status) in scalar registers and walks a STATIC
+// set of tiles per attempt (tile = g, g + G, ...; the remainder round is SPREAD over the grid, see extra_tile) with the loads of the
+// next tile in flight while the present one is reduced; the attempt ends in ONE barrier across the grid:
+//   * each workgroup folds its tiles' records (tile order) into one group record: the sum of squares into gsum[g], the seven
+//     extrema into gmon[g][7] (sc1 stores), waits for all its stores to be acknowledged, and takes a ticket (one agent-scope atomic);
+//   * the workgroup that takes the LAST ticket of the attempt adds the G sums in a fixed order (thread t: groups t, t + BLK, ...;
+//     wave butterflies; waves in order - deterministic, independent of who is last), takes scipy's accept / reject and step-size
+//     decision (rk45_decide, the function the control kernel runs) and PUBLISHES what the next attempt needs - h, cur, status, the
+//     barrier's number - as one 16-byte record replicated over PUB_COPIES cache lines; only then, off the critical path, it reduces
+//     the extrema of an accepted step, does the event bookkeeping and writes the controller back (pause_on_event: the events
+//     decide the status, so they come first);
+//   * everybody polls its copy of the record (bounded; a time-out raises the sticky flag and every workgroup leaves).
+// Coherence across the 8 XCDs as in rk4_stream_kernel: state, records and the controller move with agent-scope (sc1) loads /
+// stores; a ticket is taken only after s_waitcnt vmcnt(0) + barrier.  Needs all G workgroups resident at once (the host sizes G by
+// hipOccupancyMaxActiveBlocksPerMultiprocessor); counters are never reset between launches (arrive_base / epoch_base say where
+// they stand).  The published record carries a 24-bit hash of h beside the barrier number, so a torn read cannot pass.
+// ---------------------------------------------------------------------------------------------
+// a value that is the same in every lane, moved into scalar registers (readfirstlane)
+__device__ __forceinline__ double to_sgpr(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ int32_t to_sgpr(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t to_sgpr(int64_t v)
+{
+    return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int32_t)((uint64_t)v >> 32)) << 32) |
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)v));
+}
+constexpr int MON_STRIDE = 16;          // doubles between the grid-wide extrema (one 128-byte line each)
+constexpr int MON_OFFSET = 4096;        // grec: [0, MON_OFFSET) the workgroups' sums, then [2][NQ - 1][MON_STRIDE] extrema
+constexpr int GREC_DOUBLES = MON_OFFSET + 2 * (NQ - 1) * MON_STRIDE;
+constexpr int PUB_COPIES = 32;          // replicas of the published record, PUB_STRIDE words apart (pollers spread over channels)
+constexpr int PUB_STRIDE = 32;          // 64-bit words (256 B)
+struct Rk45Stream {
+    unsigned arrive;                    // tickets taken since the words were zeroed
+    unsigned sticky;                    // raised by a workgroup that gave up waiting
+    unsigned pad0[30];
+    unsigned grab;                      // remainder-round tiles handed out (own cache line)
+    unsigned pad1[31];
+    unsigned long long pub[PUB_COPIES * PUB_STRIDE];   // copy k: pub[k * PUB_STRIDE + 0] = bits of h_try, [+ 1] = hash24(h) << 40 | epoch << 8 | (status + 1) << 1 | cur
+};
+__device__ __forceinline__ unsigned long long pub_word(unsigned long long hbits, unsigned epoch, int status, int cur)
+{
+    const unsigned long long hash = (hbits ^ (hbits >> 24) ^ (hbits >> 48)) & 0xffffffull;
+    return (hash << 40) | ((unsigned long long)epoch << 8) | (unsigned long long)(((status + 1) & 7) << 1) | (unsigned long long)(cur & 1);
+}
+// The tiles of an attempt: `full` = tiles / G rounds are STATIC (workgroup g: tiles g, g + G, ...; the next tile's loads in flight
+// while the present one is reduced); the R = tiles mod G tiles of the remainder round are handed out by an atomic counter to whoever
+// has finished its static tiles.  The SIMDs arbitrate oldest-first, so the four workgroups of a CU finish their static tiles one
+// after the other (measured at N = 2^20: after 31 ... 65 us) and the remainder goes to the early finishers, about one per CU - a
+// static owner (every ~G/R-th workgroup) left some CUs with 18 tiles and others with 16 (profiles/r04_lab_rk45_stream.log).
+// Determinism: a static tile's sum of squares goes into its workgroup's sum (tile order), a remainder tile's into its own slot
+// gextra[e]; the barrier's last workgroup adds G + R numbers in index order - the same numbers whoever computed them; extrema are
+// exact under any order.  The counter is never reset: every attempt takes exactly R successful and G failing grabs.
+#ifdef MARL_LAB_CLOCK45  // kernel-lab diagnostic build only: s_memrealtime (100 MHz) stamps per (attempt < 64, workgroup < 2048): attempt start, tiles done, ticket taken, decision seen
+__device__ unsigned long long marl_lab_clock45[64 * 2048 * 4 + 64 * 8];   // (+ the last arriver's phases: [64][8])
+#define MARL_STAMP45(k) do { if (threadIdx.x == 0 && a < 64 && g < 2048) marl_lab_clock45[(a * 2048 + g) * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define MARL_STAMP45L(k) do { if (threadIdx.x == 0 && a < 64) marl_lab_clock45[64 * 2048 * 4 + a * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ unsigned long long marl_lab_clock45t[2048 * 8 * 8];   // tiles of attempt 20: [g][tile index < 8][phase < 8]
+#define MARL_STAMP45T(k) do { if (threadIdx.x == 0 && a == 20 && g < 2048 && ti < 8 && tile < tiles) marl_lab_clock45t[(g * 8 + ti) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MARL_STAMP45(k) do { } while (0)
+#define MARL_STAMP45L(k) do { } while (0)
+#define MARL_STAMP45T(k) do { } while (0)
+#endif
+#ifdef MARL_LAB_STREAM_PLAIN   // kernel-lab cost probe ONLY (results are wrong across XCDs): the state through the non-coherent L2s
+#define MARL_STREAM_LOAD(p) (*(p))
+#define MARL_STREAM_STORE(p, v) (*(p) = (v))
+#else
+#define MARL_STREAM_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define MARL_STREAM_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif
+#ifndef MARL_STREAM_PARK   // fields of y parked in LDS (dp45_attempt): 4 leave LDS for exactly four workgroups per CU (40 448 of 40 960 bytes)
+#define MARL_STREAM_PARK 4
+#endif
+template <int BLK, int LAYOUT, bool VD = false>
+__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8)))
+rk45_stream_kernel(double* Y0, double* Y1, double* F0, double* F1, const DevConsts* __restrict__ consts, Slab S, Rk45Ctrl* ctrl,
+                   double* grec, Rk45Stream* sync, unsigned tiles, unsigned arrive_base, unsigned epoch_base, unsigned grab_base, unsigned max_attempts,
+                   double* send = nullptr, int halo = 0)
+{
+    // send != NULL (one slab of a domain-decomposed grid; max_attempts = 1, all three bases 0): ONE attempt per launch, and the
+    // barrier's last workgroup, instead of deciding, writes the rank's message [record (8) | lower strip | upper strip] (what
+    // reduce_chunks_kernel + slab_reduce_pack_kernel did) and re-arms the counters; the all-gather and slab_unpack_control_kernel
+    // follow, and the next launch reads the common decision out of *ctrl.
+    constexpr int CPT = 1;
+    constexpr int H = 6;
+    constexpr int V = BLK - 2 * H;
+    constexpr int PARK = MARL_STREAM_PARK;
+    constexpr int NW = BLK / 64;
+    constexpr int CTRL_WORDS = (int)(sizeof(Rk45Ctrl) / 8);
+    static_assert(sizeof(Rk45Ctrl) % 8 == 0 && CTRL_WORDS <= BLK, "the controller moves as 64-bit words, one per thread");
+    static_assert(PARK >= 3, "the reduction columns of a tile use three park columns");
+    using SB = StencilBlock<BLK, CPT, true, VD>;
+    __shared__ double lds[SB::LDS_DOUBLES + PARK * CPT * BLK];
+    __shared__ double s_acc[NQ];         // this workgroup's record of the attempt (maxima negated), slot j touched by thread 32 j only
+    __shared__ double s_wsum[NW];
+    __shared__ double s_rec[NQ];         // last workgroup of a barrier: the grid's record {-, seven extrema of y_new}
+    __shared__ Rk45Ctrl sc;
+    __shared__ unsigned long long s_pub[2];
+    __shared__ int s_last, s_abort;
+    __shared__ unsigned s_next;
+    SB sb(lds, 0, consts);   // tables once per workgroup (barrier inside)
+    const unsigned G = gridDim.x, g = blockIdx.x;
+    const unsigned n_full = tiles / G, R = tiles - n_full * G;         // n_full >= 1: the host launches G <= tiles workgroups
+    double* const gsum = grec;                      // [G + R]: the workgroups' sums of squares over their static tiles, then the remainder tiles' sums
+    double* const gmon = grec + MON_OFFSET;         // [2][NQ - 1][MON_STRIDE]: the grid's seven extrema (maxima negated) by attempt parity, +inf when idle
+    // the controller as the previous launch (or rk45_init / rk45_resume) left it
+    int cur = ctrl->cur, status = ctrl->status;
+    double h = ctrl->h_try;
+    const double rtol = ctrl->rtol, atol = ctrl->atol;
+    const int pause_on_event = ctrl->pause_on_event;
+    unsigned long long* const my_pub = sync->pub + (g % PUB_COPIES) * PUB_STRIDE;
+
+
+    for (unsigned a = 0; a < max_attempts && status == ST_RUNNING; a++) {
+        const double* yin = cur ? Y1 : Y0;
+        const double* fin = cur ? F1 : F0;
+        double* yout = cur ? Y0 : Y1;
+        double* fout = cur ? F0 : F1;
+        MARL_STAMP45(0);
+#ifdef MARL_LAB_CLOCK45
+        if (threadIdx.x == 0 && g == 0 && (a == 8 || a == 56)) {   // shader clock (s_memtime) against the 100 MHz reference: the clock this kernel runs at
+            marl_lab_clock45t[2048 * 8 * 8 - 4 + (a == 8 ? 0 : 2)] = __builtin_amdgcn_s_memtime();
+            marl_lab_clock45t[2048 * 8 * 8 - 4 + (a == 8 ? 1 : 3)] = __builtin_amdgcn_s_memrealtime();
+        }
+#endif
+        double y[CPT][NF], k1[CPT][NF];
+        // (a thread's cell of tile t: local index l = out_lo + t V - H + tid; lanes outside the buffer - beyond a physical boundary, where the
+        // ghost-cell rules apply and nothing reads them - load a copy of the edge cell: no predicate, no branch, finite values)
+#define MARL_LOAD_TILE(t, tid_)                                                                                                        \
+        do {                                                                                                                           \
+            int64_t l_ = S.out_lo + (int64_t)(t) * V - H + (tid_);                                                                     \
+            l_ = l_ < 0 ? 0 : (l_ < S.n_buf ? l_ : S.n_buf - 1);                                                                       \
+            _Pragma("unroll") for (int f = 0; f < NF; f++)                                                                             \
+                y[0][f] = MARL_STREAM_LOAD(yin + at<LAYOUT>(f, l_, S.ld));                                                             \
+            _Pragma("unroll") for (int f = 0; f < NF; f++)                                                                             \
+                k1[0][f] = MARL_STREAM_LOAD(fin + at<LAYOUT>(f, l_, S.ld));                                                            \
+        } while (0)
+        {
+            int tid0 = threadIdx.x;
+            asm volatile("" : "+v"(tid0));
+            MARL_LOAD_TILE(g, tid0);
+        }
+        if ((threadIdx.x & 31) == 0) {   // thread 32 j owns s_acc[j]
+            const int j = threadIdx.x >> 5;
+            s_acc[j] = (j == 0) ? 0.0 : __builtin_inf();
+        }
+        const unsigned grab0 = grab_base + a * (R + G);
+        for (unsigned ti = 0;; ti++) {
+            unsigned tile = g + ti * G, extra = 0;
+            MARL_STAMP45T(0);
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));   // opaque: what derives from the thread index is recomputed per tile, not carried across the loop
+            if (ti >= n_full) {             // the remainder round: first come, first served
+                if (R == 0) break;
+                if (threadIdx.x == 0) s_next = __hip_atomic_fetch_add(&sync->grab, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - grab0;
+                __syncthreads();            // (also: every wave has finished the reduction of the previous tile)
+                extra = (unsigned)to_sgpr((int32_t)s_next);
+                if (extra >= R) break;
+                tile = n_full * G + extra;
+                MARL_LOAD_TILE(tile, tid);  // (no prefetch here: whoever works on the remainder has time)
+            } else {
+                // every wave has finished the reduction of the previous tile (whose columns this tile's park / cache / edge writes
+                // reuse) - or, first tile, has read the decision out of s_pub; the loads issued before it are in flight meanwhile
+                __syncthreads();
+            }
+            sb.rebind(tid);
+            double* pk = lds + SB::LDS_DOUBLES + tid;
+            double yn[CPT][NF], k7[CPT][NF], esum[CPT][NF];
+            PointAux aux[CPT];
+            {
+                const int64_t l = S.out_lo + (int64_t)tile * V - H + tid;
+                sb.set_window(l + S.goff);
+            }
+            sb.reuse_live[0] = false;
+#pragma unroll
+            for (int f = 0; f < PARK; f++) pk[f * BLK] = y[0][f];
+            MARL_STAMP45T(1);
+            dp45_attempt<BLK, CPT, false, SB, PARK>(sb, h, y, k1, yn, k7, esum, aux, DenseWeights{}, pk);
+            MARL_STAMP45T(2);
+            // everything below is recomputed from the thread index again (nothing but the results is carried across the stages)
+            int tid2 = threadIdx.x;
+            asm volatile("" : "+v"(tid2));
+            const int64_t l2 = S.out_lo + (int64_t)tile * V - H + tid2;
+            const bool owned = tid2 >= H && tid2 < BLK - H && l2 >= S.out_lo && l2 < S.out_hi;
+            double q[NQ];
+            monitors_init(q);
+            if (owned) {
+                const double* pk2 = lds + SB::LDS_DOUBLES + tid2;
+#pragma unroll
+                for (int f = 0; f < NF; f++) q[0] += dp45_err2(esum[0][f], h, f < PARK ? pk2[f * BLK] : y[0][f], yn[0][f], rtol, atol);
+                monitors_accumulate<true>(q, yn[0], aux[0].U, aux[0].W);
+            }
+            // the next tile's loads first, the stores behind them: vector memory operations return in order, so waiting for
+            // those loads does not wait for the stores' acknowledgements (write-through to memory: ~2 us)
+            // (unconditional - after the last tile it re-reads that tile: a conditional prefetch makes y, k1 of THIS tile the other
+            // operand of the loop's phi, i.e. twenty more registers live across the six evaluations)
+            MARL_LOAD_TILE(ti + 1 < n_full ? tile + G : tile, tid2);
+            if (owned) {
+#pragma unroll
+                for (int f = 0; f < NF; f++) {
+                    MARL_STREAM_STORE(yout + at<LAYOUT>(f, l2, S.ld), yn[0][f]);
+                    MARL_STREAM_STORE(fout + at<LAYOUT>(f, l2, S.ld), k7[0][f]);
+                }
+            }
+            MARL_STAMP45T(3);
+            const double r = tile_reduce_halfwaves<BLK, SB>(q, lds, tid2);   // (one barrier inside)
+            if ((tid2 & 31) == 0) {
+                const int j = tid2 >> 5;
+                if (j > 0) s_acc[j] = __builtin_fmin(s_acc[j], r);
+                else if (ti < n_full) s_acc[0] += r;
+                else __hip_atomic_store(gsum + G + extra, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            MARL_STAMP45T(4);
+        }
+#undef MARL_LOAD_TILE
+        // ---- the barrier of the attempt ----
+        MARL_STAMP45(1);
+        if ((threadIdx.x & 31) == 0) {   // the sum into this workgroup's slot; the extrema by fp64 atomic minimum (exact whatever the order)
+            const int j = threadIdx.x >> 5;
+            if (j == 0) __hip_atomic_store(gsum + g, s_acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else __hip_atomic_fetch_min(gmon + (((epoch_base + a) & 1u) * (NQ - 1) + (j - 1)) * MON_STRIDE, s_acc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __builtin_amdgcn_s_waitcnt(0);   // this thread's stores (state, record) have been acknowledged
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __syncthreads();                 // ... and everybody else's
+        if (threadIdx.x == 0) {
+            const unsigned old = __hip_atomic_fetch_add(&sync->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (old + 1u - arrive_base) == G * (a + 1u);
+            s_abort = 0;
+        }
+        MARL_STAMP45(2);
+        __syncthreads();
+        const unsigned epoch = epoch_base + a + 1u;
+        if (s_last) {   // (the whole workgroup) every workgroup's record of this attempt is in memory
+            MARL_STAMP45L(0);
+            // one round trip: the controller (one word per thread), the grid's extrema (threads 64..70), the workgroups' sums
+            // (thread t: groups t, t + BLK, ... - four per pass, issued together)
+            double* const mon = gmon + ((epoch_base + a) & 1u) * (NQ - 1) * MON_STRIDE;
+            if ((int)threadIdx.x < CTRL_WORDS)
+                reinterpret_cast<unsigned long long*>(&sc)[threadIdx.x] =
+                    __hip_atomic_load(reinterpret_cast<unsigned long long*>(ctrl) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x >= 64 && threadIdx.x < 64 + NQ - 1) {
+                const int j = threadIdx.x - 64 + 1;
+                const double v = __hip_atomic_load(mon + (j - 1) * MON_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_rec[j] = (j > NQMIN) ? -v : v;
+            }
+            double e2 = 0.0;
+            const unsigned GS = G + R;
+            for (unsigned base = 0; base < GS; base += 4 * BLK) {
+                double v[4];
+                const unsigned r0 = base + threadIdx.x, last = GS - 1;
+                const double* p0 = gsum + (r0 < GS ? r0 : last);
+                const double* p1 = gsum + (r0 + BLK < GS ? r0 + BLK : last);
+                const double* p2 = gsum + (r0 + 2 * BLK < GS ? r0 + 2 * BLK : last);
+                const double* p3 = gsum + (r0 + 3 * BLK < GS ? r0 + 3 * BLK : last);
+                asm volatile("global_load_dwordx2 %0, %4, off sc1\n\tglobal_load_dwordx2 %1, %5, off sc1\n\tglobal_load_dwordx2 %2, %6, off sc1\n\t"
+                             "global_load_dwordx2 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+                e2 += (r0 < GS) ? v[0] : 0.0;
+                e2 += (r0 + BLK < GS) ? v[1] : 0.0;
+                e2 += (r0 + 2 * BLK < GS) ? v[2] : 0.0;
+                e2 += (r0 + 3 * BLK < GS) ? v[3] : 0.0;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) e2 += __shfl_xor(e2, off, 64);
+            if ((threadIdx.x & 63) == 0) s_wsum[threadIdx.x >> 6] = e2;
+            MARL_STAMP45L(1);
+            __syncthreads();
+            if (send) {   // (uniform) domain decomposition: the slab's record and strips into the rank's message; nothing is decided here
+                if (threadIdx.x == 0) {
+                    double sumsq = 0.0;
+#pragma unroll
+                    for (int w = 0; w < NW; w++) sumsq += s_wsum[w];
+                    send[0] = sumsq;
+                    __hip_atomic_store(&sync->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+                    __hip_atomic_store(&sync->grab, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (threadIdx.x >= 64 && threadIdx.x < 64 + NQ - 1) {
+                    send[threadIdx.x - 64 + 1] = s_rec[threadIdx.x - 64 + 1];
+                    __hip_atomic_store(mon + (threadIdx.x - 64) * MON_STRIDE, __builtin_inf(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                const int n = 2 * NF * halo;
+                for (int i = threadIdx.x; i < n; i += BLK) {
+                    const int aa = i / (NF * halo), f = (i / halo) % NF, j = i % halo;
+                    const double* src = aa ? fout : yout;
+                    send[NQ + i] = __hip_atomic_load(src + at<LAYOUT>(f, S.out_lo + j, S.ld), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    send[NQ + n + i] = __hip_atomic_load(src + at<LAYOUT>(f, S.out_hi - halo + j, S.ld), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                break;
+            }
+            if (threadIdx.x == 0) {
+                double sumsq = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; w++) sumsq += s_wsum[w];
+                const bool accepted = rk45_decide(sc, sumsq, &sb.T);
+                if (!pause_on_event) {   // the status does not depend on this step's events: publish now, bookkeeping afterwards
+                    if (accepted) rk45_advance_status_no_events(sc); else if (sc.status == ST_RUNNING) rk45_prepare_attempt(sc);
+                } else {
+                    s_rec[0] = 0.0;
+                    const int fired = accepted ? rk45_events(sc, s_rec) : 0;
+                    rk45_advance_status(sc, accepted, fired);
+                }
+                const unsigned long long hb = (unsigned long long)__double_as_longlong(sc.h_try);
+                s_pub[0] = hb;
+                s_pub[1] = pub_word(hb, epoch, sc.status, sc.cur);
+                s_last = accepted ? 2 : 1;
+            }
+            MARL_STAMP45L(2);
+            __syncthreads();
+            if ((int)threadIdx.x < PUB_COPIES) {   // one 16-byte store per copy
+                unsigned long long* p = sync->pub + threadIdx.x * PUB_STRIDE;
+                const unsigned long long w0 = s_pub[0], w1 = s_pub[1];
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(__uint128_t(w0) | (__uint128_t(w1) << 64)) : "memory");
+            }
+            MARL_STAMP45L(3);
+            // off the critical path: the driver's event bookkeeping of an accepted step (lanes 0..6: one monitor each), the extrema
+            // re-armed for the attempt after next, the controller back to memory.  The next reader of either is the last workgroup
+            // of a LATER barrier, which this workgroup joins only after these stores have been acknowledged; the host reads the
+            // controller after the kernel.
+            if (!pause_on_event && s_last == 2 && threadIdx.x < 7) rk45_event_one(sc, threadIdx.x, rk45_monitor_of_record(s_rec, threadIdx.x));
+            if (threadIdx.x >= 64 && threadIdx.x < 64 + NQ - 1)
+                __hip_atomic_store(mon + (threadIdx.x - 64) * MON_STRIDE, __builtin_inf(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if ((int)threadIdx.x < CTRL_WORDS)
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(ctrl) + threadIdx.x, reinterpret_cast<unsigned long long*>(&sc)[threadIdx.x],
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            MARL_STAMP45L(4);
+        }
+        if (send) break;   // (one attempt per launch: nothing to wait for)
+        if (threadIdx.x == 0) {
+            unsigned spins = 0;
+            while (true) {
+                __uint128_t v;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(my_pub) : "memory");
+                const unsigned long long w0 = (unsigned long long)v, w1 = (unsigned long long)(v >> 64);
+                if ((unsigned)(w1 >> 8) == epoch && w1 == pub_word(w0, epoch, (int)((w1 >> 1) & 7) - 1, (int)(w1 & 1))) {
+                    s_pub[0] = w0;
+                    s_pub[1] = w1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > STREAM_SPIN_LIMIT || ((spins & 63u) == 0 && __hip_atomic_load(&sync->sticky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    __hip_atomic_store(&sync->sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_abort = 1;
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        MARL_STAMP45(3);
+        if (s_abort) break;
+        // (LDS reads are not known to be uniform: without readfirstlane h, cur and the four buffer pointers live in vector registers)
+        h = to_sgpr(__longlong_as_double((long long)s_pub[0]));
+        const int32_t flags = to_sgpr((int32_t)(s_pub[1] & 0xff));
+        status = ((flags >> 1) & 7) - 1;
+        cur = flags & 1;
+        // (the barrier in front of the next attempt's first tile - or the end of the kernel - separates these reads from thread 0's next writes)
     }
 }
 
@@ -1309,16 +1758,6 @@ __global__ void __launch_bounds__(256) slab_copy_kernel(double* __restrict__ Y0,
 //                 one quantity each after it, and lanes 0..6 of wave 0 do the event bookkeeping (rk45_event_one) one barrier
 //                 later - after the first evaluation of the NEXT attempt, whose exchange barrier orders it - or after the loop.
 //                 Per attempt: 7 barriers instead of 12 (profiles/r03_lab_sweep.log).
-__device__ __forceinline__ double to_sgpr(double v)
-{
-    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
-}
-__device__ __forceinline__ int32_t to_sgpr(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ int64_t to_sgpr(int64_t v)
-{
-    return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int32_t)((uint64_t)v >> 32)) << 32) |
-                     (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)v));
-}
 // the fields of the step controller that rk45_decide / rk45_advance_status / rk45_prepare_attempt read or write
 __device__ __forceinline__ void ctrl_to_sgpr(Rk45Ctrl& c)
 {

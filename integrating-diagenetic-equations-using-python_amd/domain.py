@@ -59,6 +59,8 @@ class HipSlabEngine:
         _abi.check(self.ctx, self.lib.marl_set_stream(self.ctx, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
                    "marl_set_stream")
         _abi.check(self.ctx, self.lib.marl_set_option(self.ctx, b"poll_interval", 32), "marl_set_option")
+        for name, value in _abi.lab_options():   # (kernel-lab A/B runs only: MARL_HIP_OPTIONS)
+            _abi.check(self.ctx, self.lib.marl_set_option(self.ctx, name.encode(), int(value)), "marl_set_option")
 
     def _call(self, name, *args):
         _abi.check(self.ctx, getattr(self.lib, name)(self.ctx, *args), name)
