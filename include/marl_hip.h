@@ -57,7 +57,13 @@ int marl_synchronize(marl_ctx* ctx);
  *   rk4_variant, rk45_variant, sweep_variant (kernel shapes; -1 = default), host_layout (device layout used behind the
  *   host-pointer entry points), poll_interval (attempts enqueued between status reads), no_reuse (1: every RHS evaluation of
  *   the fused kernels takes its full transcendental path - the input-independent worst case, for benchmarks), radau_solver
- *   (linear systems of the implicit path: 0 block parallel cyclic reduction - the default -, 1 sequential block Thomas),
+ *   (linear systems of the implicit path: 0 block parallel cyclic reduction - the default; 1 sequential block Thomas, a cross-check that
+ *   only lab builds compile in, -DMARL_LAB_BLOCK_THOMAS: an error otherwise),
+ *   rk45_stream (the adaptive loop of ONE grid: 1, the default: one launch for a whole batch of attempts - resident workgroups meeting at a
+ *   barrier in memory, rk45_stream_kernel - for grids of up to three rounds of resident workgroups (~750 000 cells on an MI355X), one launch
+ *   per attempt above; 0 never; 2 always), rk45_stream_attempts (attempts per launch of that loop at most; 4096),
+ *   dd_stream (library-side domain-decomposed loop: 0, the default: attempt + reduce + pack launches per attempt; 1 / 2: the slab's attempt as
+ *   one launch of the persistent kernel whose last workgroup packs the rank's message - measured not faster),
  *   implicit_zero_copy (1, the default: marl_integrate_radau / marl_integrate_bdf read their per-iteration scalars from coherent host
  *   memory that the kernels write and the host polls; 0: a copy and a stream synchronisation per read - bit-identical),
  *   radau_fused_solve (systems of up to 2048 unknowns: 0 = one launch per cyclic-reduction level; 1 = every level of a solve in one

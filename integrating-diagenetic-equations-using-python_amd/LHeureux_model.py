@@ -73,6 +73,33 @@ class RK45Result:
         self.t_events = t_events
 
 
+def pack_blocks(instances, length):
+    """The marl_params blocks (include/marl_params.h) of a list of instances (constructor-keyword dicts) on a column of `length`:
+    what marl_ctx_create / marl_ctx_set_params receive.  A pure function of its arguments - a rank's blocks are the corresponding
+    blocks of the unsharded sweep (tests/test_multi_rank_cpu.py)."""
+    blocks = (MarlParams * len(instances))()
+    for blk, inst in zip(blocks, instances):
+        for name in _abi.PARAM_DOUBLES[:30]:
+            setattr(blk, name, float(inst[name]))
+        blk.length = float(length)
+        blk.shallow_limit = float(inst["ShallowLimit"]) / float(inst["Xstar"])
+        blk.deep_limit = float(inst["DeepLimit"]) / float(inst["Xstar"])
+        blk.FV_switch = int(inst["FV_switch"])
+        blk.dPhi_variable = int(bool(inst.get("dPhi_variable", False)))
+    return blocks
+
+
+def instance_kwargs(pde_parms, instances):
+    """Constructor keywords of every instance of a sweep: the scenario dict overridden by each instance's entries, reduced to what the
+    constructor takes (what :meth:`LMAHeureuxPorosityDiff.from_scenario` passes on)."""
+    import inspect
+    names = {p for p in inspect.signature(LMAHeureuxPorosityDiff.__init__).parameters} - {"self", "Depths", "device"}
+    sig = inspect.signature(LMAHeureuxPorosityDiff.__init__).parameters
+    defaults = {k: sig[k].default for k in names if sig[k].default is not inspect.Parameter.empty and not k.startswith("_")
+                and k not in ("slices_all_fields", "not_too_shallow", "not_too_deep")}
+    return [defaults | {k: v for k, v in (pde_parms | inst).items() if k in names} for inst in instances]
+
+
 class LMAHeureuxPorosityDiff:
     """Model object: parameters on the device + the callables scipy / the integrators need."""
 
@@ -126,16 +153,7 @@ class LMAHeureuxPorosityDiff:
         self.not_too_deep = np.heaviside(DeepLimit / Xstar - x, 0)
 
     def _pack_blocks(self):
-        blocks = (MarlParams * len(self.instances))()
-        for blk, inst in zip(blocks, self.instances):
-            for name in _abi.PARAM_DOUBLES[:30]:
-                setattr(blk, name, float(inst[name]))
-            blk.length = float(self.Depths.length)
-            blk.shallow_limit = float(inst["ShallowLimit"]) / float(inst["Xstar"])
-            blk.deep_limit = float(inst["DeepLimit"]) / float(inst["Xstar"])
-            blk.FV_switch = int(inst["FV_switch"])
-            blk.dPhi_variable = int(bool(inst.get("dPhi_variable", False)))
-        return blocks
+        return pack_blocks(self.instances, self.Depths.length)
 
     def set_scenario(self, pde_parms):
         """The parameters of another scenario (``asdict(Map_Scenario())``-style dict, same N and max_depth / Xstar) for this

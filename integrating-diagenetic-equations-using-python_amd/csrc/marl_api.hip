@@ -24,7 +24,7 @@
 using namespace marl;
 
 static_assert(MARL_NFIELDS == NF, "field count");
-static std::string g_create_error;
+static thread_local std::string g_create_error;   // marl_ctx_create failures, per calling thread (contexts are created from worker threads too)
 
 struct marl_ctx {
     int device = 0;
@@ -389,7 +389,14 @@ int marl_set_option(marl_ctx* ctx, const char* name, int64_t value)
     else if (n == "sweep_variant") ctx->sweep_variant = value;
     else if (n == "host_layout") ctx->host_layout = value ? LAYOUT_TILED : LAYOUT_FIELD_MAJOR;
     else if (n == "poll_interval") ctx->poll = value > 0 ? value : 1;
-    else if (n == "radau_solver") ctx->radau_solver = value ? 1 : 0;
+    else if (n == "radau_solver") {
+#ifdef MARL_LAB_BLOCK_THOMAS
+        ctx->radau_solver = value ? 1 : 0;
+#else
+        if (value) return fail(ctx, -1, "marl_set_option: radau_solver = 1 (sequential block Thomas, the cross-check of the cyclic-reduction solver) is compiled into lab builds only (-DMARL_LAB_BLOCK_THOMAS)");
+        ctx->radau_solver = 0;
+#endif
+    }
     else if (n == "radau_cr") ctx->radau_cr = (value < 0) ? -1 : std::min<int64_t>(value, radau::CR_MAX_LEVELS);
     else if (n == "radau_cr_min_n") ctx->radau_cr_min_n = std::max<int64_t>(value, 4);
     else if (n == "radau_cr_small") ctx->radau_cr_small = value < 0 ? 0 : std::min<int64_t>(value, radau::CR_WG_MAX_LEVELS);
@@ -1822,12 +1829,14 @@ int pcr_solve_launch(marl_ctx* ctx, RadauWork& w, int64_t M, bool both, double* 
 // factorise  mu_r I - J  and  mu_c I - J  (block PCR: 1 + ceil(log2 N) launches; or sequential block Thomas: 1 launch)
 int radau_factor(marl_ctx* ctx, RadauWork& w, double mu_r, cplx mu_c)
 {
+#ifdef MARL_LAB_BLOCK_THOMAS
     const int64_t N = ctx->N;
     if (!w.pcr) {
         hipLaunchKernelGGL(radau::factor_kernel, dim3(2), dim3(64), 0, ctx->stream, w.J, N, mu_r, mu_c, w.Dinv_r, w.Up_r, w.Dinv_c, w.Up_c);
         LAUNCH_OK(ctx);
         return 0;
     }
+#endif
     return pcr_factor_launch(ctx, w, mu_r, mu_c, 1.0, 2);
 }
 
@@ -1835,12 +1844,14 @@ int radau_factor(marl_ctx* ctx, RadauWork& w, double mu_r, cplx mu_c)
 int radau_solve(marl_ctx* ctx, RadauWork& w, bool both)
 {
     const int64_t N = ctx->N;
+#ifdef MARL_LAB_BLOCK_THOMAS
     if (!w.pcr) {
         hipLaunchKernelGGL(radau::solve_kernel, dim3(both ? 2 : 1), dim3(64), 0, ctx->stream, w.J, N, w.Dinv_r, w.Up_r, w.Dinv_c, w.Up_c, w.rhs_r, w.rhs_c,
                            both ? 3 : 1);
         LAUNCH_OK(ctx);
         return 0;
     }
+#endif
     if (!w.cr_k) return pcr_solve_launch(ctx, w, N, both, w.rhs_r, w.rhs_c);
     if (w.plan.k && ctx->radau_fused_solve) {   // small grids: reduction levels, compact PCR and back-substitution in one launch (crpcr_solve_all)
         hipLaunchKernelGGL(radau::pcr_solve_fused_kernel, dim3(1, both ? 2 : 1), dim3(radau::PCR_FUSED_THREADS), 0, ctx->stream, N, w.nlevels, 0, w.Sr, w.Sc,

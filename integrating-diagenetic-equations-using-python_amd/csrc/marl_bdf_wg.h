@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(radau::WG_THREADS) solve_wg_kernel(int mode, c
             double rate = -1;
             if (dy_norm_old >= 0) rate = dy_norm / dy_norm_old;
             int v = 0;
-            if (rate >= 0 && (rate >= 1 || pow(rate, (double)(NEWTON_MAXITER - k)) / (1 - rate) * dy_norm > newton_tol)) v = 2;
+            if (rate >= 0 && (rate >= 1 || pow_small_int(rate, NEWTON_MAXITER - k) / (1 - rate) * dy_norm > newton_tol)) v = 2;
             else if (dy_norm == 0 || (rate >= 0 && rate / (1 - rate) * dy_norm < newton_tol)) v = 1;
             s_verdict = v;
         }

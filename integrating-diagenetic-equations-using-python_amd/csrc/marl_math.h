@@ -96,6 +96,23 @@ __device__ __forceinline__ double rcp_nr(double x)
     return __builtin_fma(r1, e, r1);
 }
 
+// x^n for a small positive integer n, rounded once: the running product is kept as an unevaluated sum hi + lo (one fma recovers the
+// rounding error of every multiplication), so the result is the correctly rounded power except in ~2^-47 of all cases - which is what
+// libm's pow(x, n) delivers and what scipy's Newton divergence tests (rate ** (NEWTON_MAXITER - k), radau.py:108 / bdf.py:60) are
+// therefore compared with on the host, in scipy and in the oracle.  OCML's pow is not correctly rounded (a knife-edge rate
+// test could fall the other way on the device).
+__host__ __device__ __forceinline__ double pow_small_int(double x, int n)
+{
+    double hi = x, lo = 0.0;
+    for (int i = 1; i < n; i++) {
+        const double p = hi * x;
+        const double e = __builtin_fma(hi, x, -p) + lo * x;
+        hi = p + e;
+        lo = (p - hi) + e;
+    }
+    return hi;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Table-driven fp64 log / exp.  OCML's log costs ~96 and pow ~224 vector instructions per call; this
 // path is fp64-VALU-bound, so both are replaced by the classic table + short polynomial scheme with

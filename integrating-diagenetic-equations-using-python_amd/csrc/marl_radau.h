@@ -233,6 +233,7 @@ __global__ void __launch_bounds__(256) fd_finish_kernel(const double* __restrict
     factor[j] = fac; h[j] = hj;
 }
 
+#ifdef MARL_LAB_BLOCK_THOMAS   // the first implementation (one lane per system: 199 VGPRs, 832 B/lane of scratch), a cross-check for lab builds only
 // ---- block-tridiagonal LU of  mu I - J  (cell-major ordering) -----------------------------------------------------------
 // Block Thomas: D'_0 = D_0; Up_i = D'_i^-1 U_i; D'_{i+1} = D_{i+1} - L_{i+1} Up_i, with D_i = mu I - J[i][1], L_i = -J[i][0],
 // U_i = -J[i][2].  D'_i is inverted by Gauss-Jordan with partial pivoting.  Stored: Dinv[i] (5x5), Up[i] (5x5).
@@ -378,6 +379,8 @@ __global__ void __launch_bounds__(64) solve_kernel(const double* __restrict__ J,
 // recurrences (one thread per unknown per level).  One launch per level: a grid-wide dependency sits between levels.
 // Accuracy against dense LU on this model's matrices (h = 1e-6 ... 0.1, condition up to 1e20): <= 6e-10 relative.
 // storage of one system: blocks are 25 T per cell
+#endif   // MARL_LAB_BLOCK_THOMAS
+
 template <class T>
 struct PcrSystem {
     T* L[2]; T* D[2]; T* U[2]; T* Dinv[2];   // ping-pong sets of the level in progress

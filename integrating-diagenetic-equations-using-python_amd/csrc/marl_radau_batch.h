@@ -133,7 +133,7 @@ __device__ __forceinline__ void radau_control_step(RadauCtl& c, const double (&g
             else {
                 const double dW_norm = sqrt(c.sumsq) / sqrt((double)(3 * n));
                 if (c.dW_norm_old >= 0) c.rate = dW_norm / c.dW_norm_old;
-                if (c.rate >= 0 && (c.rate >= 1 || pow(c.rate, (double)(NEWTON_MAXITER - c.k)) / (1 - c.rate) * dW_norm > c.newton_tol)) failed = true;
+                if (c.rate >= 0 && (c.rate >= 1 || pow_small_int(c.rate, NEWTON_MAXITER - c.k) / (1 - c.rate) * dW_norm > c.newton_tol)) failed = true;
                 else if (dW_norm == 0 || (c.rate >= 0 && c.rate / (1 - c.rate) * dW_norm < c.newton_tol)) converged = true;
                 else c.dW_norm_old = dW_norm;
             }

@@ -16,6 +16,48 @@ def shard(n_instances, rank, world):
     return (n_instances * rank) // world, (n_instances * (rank + 1)) // world
 
 
+def assign(n_instances, rank, world, mode="contiguous", cost=None):
+    """The instance indices of ``rank`` (ascending) under one of three assignments - the same on every rank, no communication:
+
+    ``contiguous``   the near-even index ranges of :func:`shard` (fixed-budget explicit sweeps: every instance costs the same)
+    ``round_robin``  rank r takes r, r + world, r + 2 world, ...: a cost that varies smoothly along the axes of a parameter grid
+                     (implicit solvers: the evaluations per scenario spread 20x, slowest where Phi0 and PhiIni are high) is spread
+                     over all ranks instead of landing on the rank that owns that end of the grid
+    ``cost``         longest-processing-time-first on the given per-instance cost estimates (largest first, each to the least
+                     loaded rank; ties by lower rank, then by lower index): for callers who know their stragglers
+    """
+    if mode == "contiguous":
+        lo, hi = shard(n_instances, rank, world)
+        return list(range(lo, hi))
+    if mode == "round_robin":
+        return list(range(rank, n_instances, world))
+    if mode == "cost":
+        c = np.asarray(cost, dtype=float)
+        if c.shape != (n_instances,):
+            raise ValueError("assign: `cost` needs one estimate per instance")
+        load = [0.0] * world
+        mine = []
+        for i in sorted(range(n_instances), key=lambda i: (-c[i], i)):
+            r = min(range(world), key=lambda r: (load[r], r))
+            load[r] += c[i]
+            if r == rank:
+                mine.append(i)
+        return sorted(mine)
+    raise ValueError(f"assign: unknown mode {mode!r}")
+
+
+def implicit_cost_proxy(base_parms, instances):
+    """A-priori cost estimate of an implicit (Radau / BDF) run of each scenario: the evaluations scipy's Radau needs on the reference's
+    own cases grow from ~390 (Phi0 0.6 / PhiIni 0.5) to ~32 000 (Phi0 = PhiIni = 0.8, where the porosity passes its pole and W changes
+    sign hundreds of times) - steeply in the larger of the two porosities.  A monotone guess, good enough to
+    keep the heavy end of a grid from landing on one rank."""
+    out = []
+    for inst in instances:
+        p = base_parms | inst
+        out.append(1.0 + 80.0 * max(0.0, max(float(p["Phi0"]), float(p["PhiIni"])) - 0.7) ** 2 * 100.0)
+    return np.array(out)
+
+
 def product_grid(**axes):
     """Cartesian product of named parameter axes -> list of override dicts (last axis fastest)."""
     names = list(axes)
@@ -28,12 +70,20 @@ class HipSweepEngine:
 
     def __init__(self, base_parms, instances, device):
         import torch
-        from .LHeureux_model import LMAHeureuxPorosityDiff
         self.torch = torch
         self.device = torch.device("cuda", device)
         self.base_parms, self.instances = dict(base_parms), [dict(i) for i in instances]
-        self.model = LMAHeureuxPorosityDiff.from_scenario(base_parms, device=device, instances=instances)
-        self.model.use_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self._model = None
+
+    @property
+    def model(self):
+        """The batched model (device constants, controllers, arenas for all instances): built on first use - integrate_bdf runs
+        single-instance contexts and never needs it."""
+        if self._model is None:
+            from .LHeureux_model import LMAHeureuxPorosityDiff
+            self._model = LMAHeureuxPorosityDiff.from_scenario(self.base_parms, device=self.device.index, instances=self.instances)
+            self._model.use_stream(self.torch.cuda.current_stream(self.device).cuda_stream)
+        return self._model
 
     def integrate_rk45(self, y0, t_span, first_step, rtol, atol, max_attempts):
         """y0: (n_local, 5N) host array.  Returns (y_final (n_local, 5N), list of RK45Result)."""
@@ -93,7 +143,9 @@ class HipSweepEngine:
         return yd.cpu().numpy()
 
     def close(self):
-        self.model.close()
+        if self._model is not None:
+            self._model.close()
+            self._model = None
 
 
 def initial_states(base_parms, instances):
@@ -107,48 +159,65 @@ def initial_states(base_parms, instances):
 
 
 def run_sweep_radau(base_parms, instances, t_span, first_step, rtol, atol, max_attempts=0, y0=None, group=None,
-                    device=None, engine_factory=None, gather=True):
+                    device=None, engine_factory=None, gather=True, balance="cost", cost=None):
     """As :func:`run_sweep_rk45` with the reference's DEFAULT solver (scipy Radau semantics, marlpde/parameters.py:213): what the
-    reference does one scenario per process (its tests loop over scenarios), sharded over the ranks with no data-path collective."""
-    return _run_sweep("integrate_radau", base_parms, instances, t_span, first_step, rtol, atol, max_attempts, y0, group, device, engine_factory, gather)
+    reference does one scenario per process (its tests loop over scenarios), spread over the ranks with no data-path collective.
+    An implicit run's cost depends on the scenario (20x between the fastest and the slowest of a parameter grid), and the slowest
+    rank sets the wall time: ``balance`` = ``"cost"`` (default: :func:`assign` by ``cost``, or by :func:`implicit_cost_proxy` when
+    none is given), ``"round_robin"`` or ``"contiguous"``.  Results come back in the order of ``instances`` whatever the assignment."""
+    return _run_sweep("integrate_radau", base_parms, instances, t_span, first_step, rtol, atol, max_attempts, y0, group, device, engine_factory, gather,
+                      balance, cost)
 
 
 def run_sweep_bdf(base_parms, instances, t_span, first_step, rtol, atol, max_attempts=0, y0=None, group=None,
-                  device=None, engine_factory=None, gather=True):
-    """As :func:`run_sweep_radau` with scipy's BDF semantics; on a GPU the shard's instances run as concurrent single runs
+                  device=None, engine_factory=None, gather=True, balance="cost", cost=None):
+    """As :func:`run_sweep_radau` with scipy's BDF semantics; on a GPU the rank's instances run as concurrent single runs
     (:meth:`HipSweepEngine.integrate_bdf`)."""
-    return _run_sweep("integrate_bdf", base_parms, instances, t_span, first_step, rtol, atol, max_attempts, y0, group, device, engine_factory, gather)
+    return _run_sweep("integrate_bdf", base_parms, instances, t_span, first_step, rtol, atol, max_attempts, y0, group, device, engine_factory, gather,
+                      balance, cost)
 
 
 def run_sweep_rk45(base_parms, instances, t_span, first_step, rtol, atol, max_attempts=0, y0=None, group=None,
-                   device=None, engine_factory=None, gather=True):
-    """Integrate every instance with adaptive RK45; ranks of ``group`` each take a contiguous shard.
+                   device=None, engine_factory=None, gather=True, balance="contiguous", cost=None):
+    """Integrate every instance with adaptive RK45; ranks of ``group`` each take a contiguous shard (``balance``: see :func:`assign`).
 
-    Returns ``(y_final, status, n_accepted, n_rejected, t_reached)`` - for ALL instances when ``gather``,
-    otherwise for the local shard.  ``engine_factory(base_parms, local_instances) -> engine`` is the test hook;
-    the default is :class:`HipSweepEngine` on ``cuda:rank``."""
-    return _run_sweep("integrate_rk45", base_parms, instances, t_span, first_step, rtol, atol, max_attempts, y0, group, device, engine_factory, gather)
+    Returns ``(y_final, status, n_accepted, n_rejected, t_reached)`` - for ALL instances, in their order, when ``gather``,
+    otherwise for the rank's own instances (``assign(...)`` order).  ``engine_factory(base_parms, local_instances) -> engine`` is
+    the test hook; the default is :class:`HipSweepEngine` on ``cuda:rank``."""
+    return _run_sweep("integrate_rk45", base_parms, instances, t_span, first_step, rtol, atol, max_attempts, y0, group, device, engine_factory, gather,
+                      balance, cost)
 
 
-def _run_sweep(method, base_parms, instances, t_span, first_step, rtol, atol, max_attempts, y0, group, device, engine_factory, gather):
+def _run_sweep(method, base_parms, instances, t_span, first_step, rtol, atol, max_attempts, y0, group, device, engine_factory, gather,
+               balance="contiguous", cost=None):
     import torch.distributed as dist
     on = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank(group) if on else 0
     world = dist.get_world_size(group) if on else 1
-    lo, hi = shard(len(instances), rank, world)
-    local = list(instances[lo:hi])
+    if balance == "cost" and cost is None:
+        cost = implicit_cost_proxy(base_parms, instances)
+    mine = assign(len(instances), rank, world, balance, cost)
+    local = [instances[i] for i in mine]
     if y0 is None:
         y0 = initial_states(base_parms, instances)
     if engine_factory is None:
         dev = int(os.environ.get("LOCAL_RANK", rank)) if device is None else device   # one process per GPU
         engine_factory = lambda bp, inst: HipSweepEngine(bp, inst, dev)  # noqa: E731
-    engine = engine_factory(base_parms, local)
-    y, res = getattr(engine, method)(np.asarray(y0)[lo:hi], t_span, first_step, rtol, atol, max_attempts)
-    engine.close()
+    y0 = np.asarray(y0)
+    if local:
+        engine = engine_factory(base_parms, local)
+        y, res = getattr(engine, method)(y0[mine], t_span, first_step, rtol, atol, max_attempts)
+        engine.close()
+    else:   # (more ranks than instances)
+        y, res = np.empty((0,) + y0.shape[1:]), []
     summary = np.array([[r.status, r.n_accepted, r.n_rejected, r.t_reached] for r in res], dtype=float).reshape(len(local), 4)
     if gather and world > 1:
         parts = [None] * world
-        dist.all_gather_object(parts, (y, summary), group=group)
-        y = np.concatenate([p[0] for p in parts])
-        summary = np.concatenate([p[1] for p in parts])
+        dist.all_gather_object(parts, (mine, y, summary), group=group)
+        y_all = np.empty((len(instances),) + y0.shape[1:])
+        s_all = np.empty((len(instances), 4))
+        for idx, yy, ss in parts:   # back into the order of `instances`
+            y_all[idx] = yy
+            s_all[idx] = ss
+        y, summary = y_all, s_all
     return y, summary[:, 0].astype(int), summary[:, 1].astype(int), summary[:, 2].astype(int), summary[:, 3]

@@ -247,14 +247,21 @@ def test_set_scenario_equals_a_fresh_model():
     from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff
     N = 200
     pa, pb = scenario("A", N), scenario("matlab", N) | {"dPhi_variable": True}
+    #  scenarios whose COLUMN differs: another depth scale Xstar (with Tstar = Xstar / sedimentation rate) and another max_depth -
+    # the grid length max_depth / Xstar, delta_x, the cell centres and the depth masks must follow, as in a fresh model
+    pc = scenario("A", N) | {"Xstar": 1000.0, "Tstar": 10000.0}
+    pd = scenario("default", N) | {"max_depth": 400.0}
     rng = np.random.default_rng(3)
     eq = LMAHeureuxPorosityDiff.from_scenario(pa, device=0)
-    for p in (pb, pa):
+    for p in (pb, pc, pd, pa):
         eq.set_scenario(p)
         fresh = LMAHeureuxPorosityDiff.from_scenario(p, device=0)
         y0 = np.concatenate([np.full(N, p[k]) for k in ("CAIni", "CCIni", "cCaIni", "cCO3Ini", "PhiIni")]) * (1 + 0.01 * rng.standard_normal(5 * N))
-        for name in ("Da", "presum", "rhorat", "dPhi_fixed", "mask_lo", "mask_hi"):
-            assert getattr(eq, name) == getattr(fresh, name)
+        assert eq.Depths.length == fresh.Depths.length == p["max_depth"] / p["Xstar"]
+        assert np.array_equal(eq.Depths.axes_coords[0], fresh.Depths.axes_coords[0])
+        assert np.array_equal(eq.not_too_shallow, fresh.not_too_shallow) and np.array_equal(eq.not_too_deep, fresh.not_too_deep)
+        for name in ("Da", "presum", "rhorat", "dPhi_fixed", "mask_lo", "mask_hi", "delta_x"):
+            assert getattr(eq, name) == getattr(fresh, name), name
         assert np.array_equal(eq.fun(0.0, y0), fresh.fun(0.0, y0))
         a, b = eq.integrate_rk45(y0, (0.0, 2e-4), 1e-6, 1e-3, 1e-3), fresh.integrate_rk45(y0, (0.0, 2e-4), 1e-6, 1e-3, 1e-3)
         assert (a.n_accepted, a.n_rejected) == (b.n_accepted, b.n_rejected) and np.array_equal(a.y[:, -1], b.y[:, -1])

@@ -38,6 +38,23 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert x["rk4_N1048576_no_reuse"]["n_ranks"] == 2 and j["roofline"]["frac_reuse_off"] > 0
 
 
+def test_bench_five_ranks_rehearsal_on_one_gpu():
+    """The rank launch, port, deadline, sharding and gather logic at a rank count near the node's 8: FIVE ranks on cuda:0 (a gpurun box
+    admits six GPU processes at once, and this test process is one of them), gloo collectives, reduced extras
+    (MARL_BENCH_LIGHT_EXTRAS).  Five does not divide the grid or the sweep: uneven slabs, uneven halo owners."""
+    p, lines = _run(["--gpus", "5", "--steps", "8", "--warmup", "2", "--no-cpu-baseline"],
+                    {"MARL_BENCH_BACKEND": "gloo", "MARL_BENCH_ONE_DEVICE": "1", "MARL_BENCH_EXTRAS_DEADLINE": "600", "MARL_BENCH_LIGHT_EXTRAS": "1"}, 1000)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 5 and j["scaling"] == "weak" and j["extras_timed_out"] is False and j["value"] > 1e9
+    x = j["extra"]
+    assert not [k for k in x if k.endswith("_error")], {k: v for k, v in x.items() if k.endswith("_error")}
+    assert x["BASELINE_configs2_3_sweep_rk45"]["instances_total"] == 5 * 256 and x["BASELINE_configs2_3_sweep_rk45"]["n_ranks"] == 5
+    dd = x["BASELINE_configs4_dd_rk45"]
+    assert dd["n_ranks"] == 5 and "all_gather" in dd["transport"] and dd["accepted_steps"] + dd["rejected_steps"] == 60
+
+
 def test_bench_watchdog_marks_the_line_and_can_exit_nonzero():
     """A deadline of 0 s fires while the first extra runs: the headline line must come out once, marked at top level, and the
     exit code is the one MARL_BENCH_TIMEOUT_RC asks for (0 by default: the headline was measured before the extras started)."""

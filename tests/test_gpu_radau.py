@@ -61,8 +61,14 @@ def _close_counts(res, nfev, njev, nlu, steps):
 @pytest.mark.parametrize("groups", ["scipy", None])
 @pytest.mark.parametrize("name", ["A", "matlab", "A_N64_tight"])
 def test_radau_reproduces_scipy_on_the_reference_rhs(oracle, name, groups, solver):
+    from marlpde_amd import _abi
     g, p, eq = _model(name)
-    eq.set_option("radau_solver", solver)
+    try:
+        eq.set_option("radau_solver", solver)
+    except _abi.MarlError as e:   # (the block-Thomas cross-check is compiled into lab builds only since round 4: -DMARL_LAB_BLOCK_THOMAS)
+        assert solver == 1 and "lab builds only" in str(e)
+        eq.close()
+        pytest.skip("radau_solver = 1 is not compiled into the shipped library")
     N = int(g["N"])
     grp = oracle.scipy_groups(N) if groups == "scipy" else None
     res = eq.integrate_radau(g["y0"], tuple(g["t_span"]), float(g["first_step"]), float(g["rtol"]), float(g["atol"]), t_eval=g["t_span"],

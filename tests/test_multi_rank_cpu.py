@@ -83,6 +83,81 @@ def test_sweep_shards_without_collectives_and_gathers(oracle):
             assert np.array_equal(y[i], yref) and (acc[i], rej[i]) == (st.n_accepted, st.n_rejected) and t[i] == st.t
 
 
+def test_assignment_modes_and_the_config4_sweep_over_eight_ranks():
+    """BASELINE configs[3]: 32 768 instances over 8 ranks.  Every assignment mode partitions [0, 32 768) exactly; a rank's parameter
+    blocks (what marl_ctx_create receives) are the corresponding blocks of the unsharded sweep, byte for byte; a skewed cost model is
+    balanced by the cost-sorted assignment and by round robin, not by contiguous ranges."""
+    from marlpde_amd.LHeureux_model import instance_kwargs, pack_blocks
+    from marlpde_amd.sweep import assign, implicit_cost_proxy, product_grid, shard
+    n, world = 32768, 8
+    insts = product_grid(Phi0=np.linspace(0.5, 0.8, 32), PhiIni=np.linspace(0.5, 0.8, 32), k3=np.logspace(-2, -1, 32))
+    for d in insts:
+        d.update(PhiNR=d["PhiIni"], k4=d["k3"])
+    assert len(insts) == n
+    base = scenario("default", 1024)
+    cost = implicit_cost_proxy(base, insts)
+    assert cost.min() == 1.0 and cost.max() > 50 * cost.min()
+    for mode in ("contiguous", "round_robin", "cost"):
+        parts = [assign(n, r, world, mode, cost) for r in range(world)]
+        assert np.array_equal(np.sort(np.concatenate(parts)), np.arange(n)), mode
+        assert all(p == sorted(p) for p in parts)
+        if mode != "cost":
+            assert [len(p) for p in parts] == [4096] * 8
+    assert [assign(n, r, world) for r in range(world)] == [list(range(*shard(n, r, world))) for r in range(world)]
+    load = {mode: np.array([cost[assign(n, r, world, mode, cost)].sum() for r in range(world)]) for mode in ("contiguous", "round_robin", "cost")}
+    assert load["contiguous"].max() > 2.0 * load["contiguous"].mean()          # the rank that owns the Phi0 = 0.8 end of the grid
+    assert load["round_robin"].max() < 1.02 * load["round_robin"].mean()
+    assert load["cost"].max() < 1.001 * load["cost"].mean()
+    L = base["max_depth"] / base["Xstar"]
+    full = bytes(pack_blocks(instance_kwargs(base, insts), L))
+    blk = len(full) // n
+    for mode in ("contiguous", "cost"):
+        for r in (0, 3, 7):
+            mine = assign(n, r, world, mode, cost)
+            local = bytes(pack_blocks(instance_kwargs(base, [insts[i] for i in mine]), L))
+            assert local == b"".join(full[i * blk:(i + 1) * blk] for i in mine), (mode, r)
+
+
+def _balanced_sweep_worker(rank, world, N, insts, balance, cost):
+    from cpu_engines import OracleSweepEngine
+    from marlpde_amd.sweep import assign, run_sweep_radau
+    base = scenario("default", N)
+    seen = []
+
+    def factory(bp, inst):
+        seen.extend(inst)
+        return OracleSweepEngine(bp, inst)
+    y, status, acc, rej, t = run_sweep_radau(base, insts, (0.0, 0.02), 1e-6, 1e-3, 1e-3, engine_factory=factory, balance=balance, cost=cost)
+    return y, status, acc, rej, seen, assign(len(insts), rank, world, balance, cost)
+
+
+@pytest.mark.parametrize("balance", ["round_robin", "cost"])
+def test_balanced_implicit_sweep_returns_results_in_input_order(oracle, balance):
+    """run_sweep_radau over 3 ranks with a skewed cost model: every rank integrates exactly the instances assign() gives it, and every
+    rank ends with ALL results in the order of `instances` - equal to the oracle instance by instance."""
+    from marlpde_amd.sweep import product_grid
+    N, world = 24, 3
+    insts = product_grid(Phi0=[0.5, 0.55, 0.6, 0.65, 0.7, 0.75, 0.8])
+    for d in insts:
+        d.update(PhiIni=d["Phi0"], PhiNR=d["Phi0"])
+    cost = [1, 1, 1, 1, 2, 9, 30]
+    out = _spawn(_balanced_sweep_worker, world, N, insts, balance, cost)
+    base = scenario("default", N)
+    owners = [out[r][5] for r in range(world)]
+    assert sorted(i for o in owners for i in o) == list(range(len(insts)))
+    if balance == "cost":
+        assert owners[0] == [6] and 5 in owners[1]            # the heaviest alone, the second heaviest on the next rank
+    for r in range(world):
+        y, status, acc, rej, seen, mine = out[r]
+        assert seen == [insts[i] for i in mine]
+        assert y.shape == (len(insts), 5 * N) and list(status) == [0] * len(insts)
+        for i, inst in enumerate(insts):
+            p = base | inst
+            y0 = np.repeat([p["CAIni"], p["CCIni"], p["cCaIni"], p["cCO3Ini"], p["PhiIni"]], N)
+            yref, st, *_ = oracle.radau(oracle.params_from_dict(p), N, y0, 0.0, 0.02, 1e-6, 1e-3, 1e-3)
+            assert np.array_equal(y[i], yref) and (acc[i], rej[i]) == (st.n_accepted, st.n_rejected), (r, i)
+
+
 def _radau_sweep_worker(rank, world, N, insts):
     from cpu_engines import OracleSweepEngine
     from marlpde_amd.sweep import run_sweep_radau, shard
@@ -124,13 +199,13 @@ def _dd_worker(rank, world, N, t1, first_step, rtol, atol, max_attempts):
     return y.numpy(), (st.status, st.n_accepted, st.n_rejected, st.nfev, st.t), (dd.begin, dd.end)
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
 def test_domain_decomposition_matches_single_grid(oracle, world):
     """Ranks exchange 6-cell halos once per attempt and all-gather one record each; every rank takes the same
-    accept/reject decisions, and the result equals the single-grid integration."""
+    accept/reject decisions, and the result equals the single-grid integration.  (8 = the rank count of BASELINE configs[4].)"""
     from marlpde_amd.domain import partition
     assert partition(10, 3) == [(0, 3), (3, 6), (6, 10)]
-    N = 50
+    N = 50 if world < 8 else 72
     p = scenario("A", N)
     dx2 = ((p["max_depth"] / p["Xstar"]) / N) ** 2
     t1, h0, rtol, atol = 30 * dx2, 0.4 * dx2, 1e-4, 1e-6

@@ -1,5 +1,7 @@
+"""Cyclic-reduction tail launches on / off, Radau Scenario A over grid sizes (needs a GPU):  python3 tools/radau_cr_tail_ab.py  (any working directory)"""
 import sys, os, time
-sys.path[:0] = [os.getcwd(), os.path.join(os.getcwd(), "tests")]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import numpy as np
 from common import scenario
 from marlpde_amd.LHeureux_model import LMAHeureuxPorosityDiff

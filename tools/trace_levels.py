@@ -1,5 +1,18 @@
-import csv, glob, sys, collections
-f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+"""Per-kernel totals and inter-kernel gaps from a rocprofv3 --kernel-trace run.
+
+    python3 tools/trace_levels.py <rocprofv3 output directory>     (the directory given to rocprofv3 -d; any working directory)
+"""
+import collections
+import csv
+import glob
+import sys
+
+if len(sys.argv) != 2:
+    sys.exit(__doc__)
+found = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)
+if not found:
+    sys.exit(f"trace_levels.py: no *kernel_trace.csv under {sys.argv[1]}")
+f = found[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 agg = collections.defaultdict(lambda: [0, 0.0])
