@@ -92,6 +92,7 @@ struct marl_ctx {
     // options
     int64_t rk4_variant = -1, rk45_variant = -1, sweep_variant = -1, host_layout = LAYOUT_TILED, poll = 64;
     int64_t rk4_stream = 1;     // the fixed-step loop of one grid as ONE dataflow launch (rk4_stream_kernel): 0 never, 1 large grids, 2 always
+    int64_t rk4_small = 1;      // grids of up to two workgroups per CU at 16 steps per launch: the build of marl_rk4_small.hip (0: the common one)
     int64_t rk4_stream_third = 1;   // an odd number of levels goes through a third state buffer, so that no whole-state copy follows (0: copy)
     double* stream_c = nullptr;
     size_t stream_c_cap = 0;
@@ -410,6 +411,7 @@ int marl_set_option(marl_ctx* ctx, const char* name, int64_t value)
     else if (n == "rk45_stream") ctx->rk45_stream = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "dd_stream") ctx->dd_stream = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "rk45_stream_attempts") ctx->rk45_stream_attempts = value < 1 ? 1 : std::min<int64_t>(value, 1 << 20);
+    else if (n == "rk4_small") ctx->rk4_small = value ? 1 : 0;
     else if (n == "rk4_stream_third") ctx->rk4_stream_third = value ? 1 : 0;
     else if (n == "rk4_stream_test_raise") ctx->sq_test_raise = value != 0;
     else if (n == "rk4_stream_max_items") ctx->sq_max_items = value > 0 ? std::min<int64_t>(value, 0x7fffffff) : 0x7fffffff;
@@ -534,6 +536,9 @@ static void launch_rk4_t(marl_ctx* ctx, const double* yin, double* yout, int lay
 constexpr int kVdRk4Variant = 2;    // {256, 1, 4}
 constexpr int kVdRk45Variant = 0;   // {256, 1}
 
+extern "C" int marl_small_rk4_16(int tiled, unsigned grid, hipStream_t stream, const double* yin, double* yout, const void* consts, const int64_t slab5[5],
+                                 double dt);   // marl_rk4_small.hip
+
 // nsteps: steps fused in this launch - the variant's own depth, or a smaller instantiated one for the remainder
 static int launch_rk4(marl_ctx* ctx, int v, int nsteps, const double* yin, double* yout, int layout, double dt)
 {
@@ -543,7 +548,25 @@ static int launch_rk4(marl_ctx* ctx, int v, int nsteps, const double* yin, doubl
         case 2: launch_rk4_t<256, 1, 2>(ctx, yin, yout, layout, dt); break;
         case 4: if (ctx->var_dphi) launch_rk4_t<256, 1, 4, true>(ctx, yin, yout, layout, dt); else launch_rk4_t<256, 1, 4>(ctx, yin, yout, layout, dt); break;
         case 8: launch_rk4_t<256, 1, 8>(ctx, yin, yout, layout, dt); break;
-        case 16: launch_rk4_t<256, 1, 16>(ctx, yin, yout, layout, dt); break;
+        case 16: {
+            // grids whose workgroups fit the chip at TWO per CU (N <= 65 536 on 256 CUs: BASELINE configs[1]) take the build of this kernel
+            // that trades occupancy for registers and ILP (marl_rk4_small.hip: 3.43 against 3.65 us per step at N = 65 536); with a third
+            // workgroup per CU that build needs a second round (N = 98 304: 6.39 against 4.47 us) - those keep the four-waves-per-SIMD one
+            const int64_t n = ctx->slab.out_hi - ctx->slab.out_lo, V = 256 - 8 * 16, tiles = (n + V - 1) / V;
+            if (!ctx->cus) {
+                hipDeviceProp_t prop;
+                HIP_OK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+                ctx->cus = prop.multiProcessorCount;
+            }
+            if (ctx->rk4_small && tiles <= 2 * (int64_t)ctx->cus) {
+                const int64_t slab5[5] = {ctx->slab.n_buf, ctx->slab.goff, ctx->slab.ld, ctx->slab.out_lo, ctx->slab.out_hi};
+                const int e = marl_small_rk4_16(layout == LAYOUT_TILED, (unsigned)tiles, ctx->stream, yin, yout, ctx->dconsts, slab5, dt);
+                if (e != 0) return fail(ctx, -100 - e, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+                return 0;
+            }
+            launch_rk4_t<256, 1, 16>(ctx, yin, yout, layout, dt);
+            break;
+        }
         default: return fail(ctx, -1, "rk4: %d steps per launch not instantiated", nsteps);
     }
     LAUNCH_OK(ctx);
