@@ -278,6 +278,7 @@ struct PointLocal {
     double Q4, DaR;             // porosity: W - Phi dW/dPhi-part (:495), Da (1-Phi)(coA - lambda coC)
     double Wd;                  // W den (Peclet numbers; only read when fv_active)
     bool upw, fv_active;
+    bool fv_solutes;            // wave-uniform: some lane of the wave has a solute Peclet number >= PECLET_MIN
 };
 
 // uc: the cell's five values.  in_mask: cell inside the dissolution zone.  K: hot constants (registers); C: the
@@ -412,7 +413,11 @@ __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask
         const bool under = O3 < 1.0;
         tA = O3 - O3;                               // 0, or NaN for a non-finite O3 (keeps the reference's NaN visible)
         if (!under || in_mask) {
+#ifdef MARL_ABLATE_POWA   // kernel-lab builds only
+            const double pwA = fabs(O3 - 1.0) * (under ? K.m2 : K.m1);
+#else
             const double pwA = pow_sat(fabs(O3 - 1.0), under ? K.m2 : K.m1, T);
+#endif
             tA = (LEGACY ? (under ? 1.0 : -K.nu1) : (under ? K.Da : -K.Da_nu1)) * pwA;  // [Da] ((1-O3)^m2 * mask  |  -nu1 (O3-1)^m1): DA = CA tA below
         }
         if (K.generic_p0) {
@@ -449,11 +454,20 @@ __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask
     // ---- Fiadeiro-Veronis weights (:433-462) all vanish when every |Pe| < PECLET_MIN (always on fine grids)
     bool fv_active = false;
     pl.Wd = 0.0;
+#ifdef MARL_ABLATE_FV   // kernel-lab builds only: central gradients throughout
+    fv_check = false;
+#endif
+    pl.fv_solutes = false;
     if (fv_check) {   // wave-uniform
         asm volatile("");   // a real branch (its five cheap operations would otherwise be speculated into every evaluation)
         const double Wd = W * den;
-        const double pmax = fmax(fabs(Wd) * K.pe_smax, wpe);
+        const double psol = fabs(Wd) * K.pe_smax;   // the larger of the two solutes' |Peclet|
+        const double pmax = fmax(psol, wpe);
         fv_active = !(pmax < PECLET_MIN);
+        // wave-uniform: does ANY lane need a weight for cCa / cCO3?  Their diffusion coefficients are ~200x the porosity's, so from
+        // N ~ 100 cells on only the porosity's Peclet number reaches PECLET_MIN (every BASELINE size) - point_rates then evaluates one
+        // sigma instead of three (a sigma of 0 gives the central gradient bit for bit, so nothing changes but the instruction count)
+        pl.fv_solutes = __builtin_amdgcn_ballot_w64(!(psol < PECLET_MIN)) != 0;
         pl.Wd = Wd;
         if constexpr (MODE == TR_FILL || MODE == TR_AUTO) { if (!reuse) pc.fv_quiet = pmax < 0.9 * PECLET_MIN; }  // in range, Pe moves by < 1e-3 relative
     } else if constexpr (MODE == TR_FILL || MODE == TR_AUTO) {
@@ -522,10 +536,17 @@ __device__ __forceinline__ void point_rates(const double (&uc)[NF], const double
     } else {
         const double W = pl.W, Wd = pl.Wd;
         const double pe_Phi = VD ? K.pe_Phi * (K.dPhi * rcp_nr(dPhi_cell())) : K.pe_Phi;   // delta_x / (2 dPhi)
-        const double s_c = fv_sigma<SERIES>(Wd * K.pe_cCa, W, T), s_o = fv_sigma<SERIES>(Wd * K.pe_cCO3, W, T), s_p = fv_sigma<SERIES>(W * pe_Phi, W, T);
-        cg = ((1.0 - s_c) * c_f + (1.0 + s_c) * c_b) * K.hdx;
-        og = ((1.0 - s_o) * o_f + (1.0 + s_o) * o_b) * K.hdx;
+        const double s_p = fv_sigma<SERIES>(W * pe_Phi, W, T);
         pg = ((1.0 - s_p) * p_f + (1.0 + s_p) * p_b) * K.hdx;
+        if (pl.fv_solutes) {   // wave-uniform (see point_local)
+            asm volatile("");
+            const double s_c = fv_sigma<SERIES>(Wd * K.pe_cCa, W, T), s_o = fv_sigma<SERIES>(Wd * K.pe_cCO3, W, T);
+            cg = ((1.0 - s_c) * c_f + (1.0 + s_c) * c_b) * K.hdx;
+            og = ((1.0 - s_o) * o_f + (1.0 + s_o) * o_b) * K.hdx;
+        } else {               // both sigmas are 0 in every lane: ((1 - 0) c_f + (1 + 0) c_b) hdx, the same bits
+            cg = (c_f + c_b) * K.hdx;
+            og = (o_f + o_b) * K.hdx;
+        }
     }
     const double h2 = pg * pl.h2f;                                      // common_helper2 (:472-473)
     const double Hc = K.dCa * __builtin_fma(h2, cg, pl.h1x * c_d);      // (:474-475)

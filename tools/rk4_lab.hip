@@ -35,6 +35,7 @@ int main(int argc, char** argv)
     p.FV_switch = 1;
     marl_ctx* ctx = nullptr;
     if (marl_ctx_create(&p, 1, N, 0, &ctx)) { printf("create failed: %s\n", marl_last_error(nullptr)); return 1; }
+    if (argc > 3 && atoi(argv[3])) marl_set_option(ctx, "no_reuse", 1);   // every evaluation takes its full path (the sweeps' regime)
     std::vector<double> y(5 * N);
     const double L = p.length, ini[5] = {0.6, 0.3, p.cCa0, p.cCO30, 0.8};
     for (int f = 0; f < 5; f++)
