@@ -19,11 +19,20 @@ python3 bench.py --no-cpu-baseline --no-extras --n 65536 > "$out/bench_n65536.js
 echo "benches done"
 [ "$quick" = "quick" ] && exit 0
 # kernel-trace statistics per workload (short runs: the trace of every dispatch is kept)
-rocprofv3 --kernel-trace --stats -d "$out/stats_default" --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras > "$out/stats_default.log" 2>&1
-rocprofv3 --kernel-trace --stats -d "$out/stats_n65536" --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras --n 65536 > "$out/stats_n65536.log" 2>&1
+# (the bench line of every TRACED run is kept beside the untraced one - traced_<workload>.json: `ms_per_step` of the run whose kernel times
+# the statistics table holds; tools/summarize_profiles.py puts the two side by side)
+rocprofv3 --kernel-trace --stats -d "$out/stats_default" --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras > "$out/traced_default.json" 2> "$out/stats_default.log"
+rocprofv3 --kernel-trace --stats -d "$out/stats_n65536" --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras --n 65536 > "$out/traced_n65536.json" 2> "$out/stats_n65536.log"
 for w in sweep_rk45 rk45_single sweep_rk4 dd_rk45; do
-  rocprofv3 --kernel-trace --stats -d "$out/stats_$w" --output-format csv -- python3 bench.py --no-cpu-baseline --workload $w --steps 400 > "$out/stats_$w.log" 2>&1
+  rocprofv3 --kernel-trace --stats -d "$out/stats_$w" --output-format csv -- python3 bench.py --no-cpu-baseline --workload $w --steps 400 > "$out/traced_$w.json" 2> "$out/stats_$w.log"
+  python3 bench.py --no-cpu-baseline --workload $w --steps 400 > "$out/bench400_$w.json" 2> /dev/null   # the same command untraced
 done
+# the domain-decomposed loop at the 8-GPU shard size with a real ncclAllGather in the stream (one-rank communicator), and the persistent
+# single-grid loop at a size where it is the default
+MARL_DD_TRANSPORT=rccl1 rocprofv3 --kernel-trace --stats -d "$out/stats_dd_shard" --output-format csv -- python3 bench.py --no-cpu-baseline --workload dd_rk45 --n 524288 --steps 400 > "$out/traced_dd_shard.json" 2> "$out/stats_dd_shard.log"
+MARL_DD_TRANSPORT=rccl1 python3 bench.py --no-cpu-baseline --workload dd_rk45 --n 524288 --steps 400 > "$out/bench400_dd_shard.json" 2> /dev/null
+rocprofv3 --kernel-trace --stats -d "$out/stats_rk45_n524288" --output-format csv -- python3 bench.py --no-cpu-baseline --workload rk45_single --n 524288 --steps 400 > "$out/traced_rk45_n524288.json" 2> "$out/stats_rk45_n524288.log"
+python3 bench.py --no-cpu-baseline --workload rk45_single --n 524288 --steps 400 > "$out/bench400_rk45_n524288.json" 2> /dev/null
 # the implicit path (the reference's DEFAULT solver): kernel statistics of single Radau runs (N = 200 / 16 000 / 64 000), BDF and a sweep;
 # HBM counters of the cyclic-reduction kernels on the large grid (one counter per pass)
 rocprofv3 --kernel-trace --stats -d "$out/stats_radau_single" --output-format csv -- python3 tools/radau_profile.py single > "$out/stats_radau_single.log" 2>&1

@@ -247,5 +247,25 @@ for f in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
         open(os.path.join(dst, f"{tag}_{os.path.basename(f)}"), "w").write(line[-1] + "\n")
         j = json.loads(line[-1])
         print(os.path.basename(f), "%.4e" % j["value"], "frac %.3f" % j.get("roofline", {}).get("frac", 0))
+# ---- traced against untraced: the bench line of the run that was traced beside the same command without the profiler ----------------
+side = {}
+for f in sorted(glob.glob(os.path.join(src, "traced_*.json"))):
+    wl = os.path.basename(f)[len("traced_"):-len(".json")]
+    line = [ln for ln in open(f).read().strip().splitlines() if ln.startswith("{")]
+    if not line:
+        continue
+    t = json.loads(line[-1])
+    e = {"traced_ms_per_step": t["ms_per_step"], "traced_value": t["value"], "steps": t["steps"]}
+    for cand in (f"bench400_{wl}.json", f"bench_{wl}.json"):   # the same command untraced (default / n65536: the bench line itself)
+        g = os.path.join(src, cand)
+        if os.path.exists(g) and open(g).read().strip():
+            u = json.loads(open(g).read().strip().splitlines()[-1])
+            e.update(untraced_ms_per_step=u["ms_per_step"], untraced_value=u["value"], untraced_steps=u["steps"], untraced_file=cand)
+            break
+    side[wl] = e
+if side:
+    json.dump({"what": "ms_per_step of the traced run (whose per-kernel times the *_rocprofv3_kernel_stats_<workload>.csv tables hold) beside the same "
+                       "command untraced, so that profiles/ alone reproduces each bench line (tools/profile_round.sh)", "workloads": side},
+              open(os.path.join(dst, f"{tag}_traced_vs_untraced.json"), "w"), indent=1)
 for k, e in hbm["kernels"].items():
     print(k[:70], {a: (round(b, 1) if isinstance(b, float) else b) for a, b in e.items()})
