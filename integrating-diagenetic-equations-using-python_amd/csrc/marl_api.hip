@@ -2849,12 +2849,15 @@ extern "C" int marl_sweep_radau_events_dev(marl_ctx* ctx, double* y_dev, double 
         const int64_t todo = nrun < 0 ? B : nrun;
         const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(todo, (int64_t)ctx->cus)));
         const int32_t* run_list = nrun < 0 ? nullptr : reinterpret_cast<const int32_t*>(wg_next + 2);
-        if (ctx->var_dphi)
-            hipLaunchKernelGGL(radau_wg_kernel<true>, grid, dim3(WG_THREADS), 0, ctx->stream, dctl, B, N, ww, ctx->dconsts, atol, P, E3[0], E3[1], E3[2], wg_next,
-                               hybrid, dcounts, dlists, dtev, run_list, todo);
-        else
-            hipLaunchKernelGGL(radau_wg_kernel<false>, grid, dim3(WG_THREADS), 0, ctx->stream, dctl, B, N, ww, ctx->dconsts, atol, P, E3[0], E3[1], E3[2], wg_next,
-                               hybrid, dcounts, dlists, dtev, run_list, todo);
+#define MARL_WG_LAUNCH(VD_, H_)                                                                                                             \
+        hipLaunchKernelGGL((radau_wg_kernel<VD_, H_>), grid, dim3(WG_THREADS), 0, ctx->stream, dctl, B, N, ww, ctx->dconsts, atol, P, E3[0], E3[1], E3[2], \
+                           wg_next, dcounts, dlists, dtev, run_list, todo)
+        if (ctx->var_dphi) {
+            if (hybrid == 0) MARL_WG_LAUNCH(true, 0); else if (hybrid == 1) MARL_WG_LAUNCH(true, 1); else MARL_WG_LAUNCH(true, 2);
+        } else {
+            if (hybrid == 0) MARL_WG_LAUNCH(false, 0); else if (hybrid == 1) MARL_WG_LAUNCH(false, 1); else MARL_WG_LAUNCH(false, 2);
+        }
+#undef MARL_WG_LAUNCH
     };
     if (use_wg) {
         launch_wg(0, -1);

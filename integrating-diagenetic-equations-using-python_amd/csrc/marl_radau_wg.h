@@ -147,13 +147,16 @@ __device__ __forceinline__ double wg_sum(double ss, double* red)
 // states; 2 x 9 cyclic-reduction levels over all cells), and the launch kernels of marl_radau.h do them over work lists as before.  An
 // instance's host cycles drop from one per ACTION (~4000 for the slowest of 512 scenarios) to one per Jacobian / factorisation.
 // counts / lists: the work lists of marl_radau_batch.h (L_JAC, L_LU, L_RUNNING); g_dense / t_events: event root finding (may be NULL).
-template <bool VD>
+// HYBRID is a template parameter (round 4): the instantiation the sweeps use by default (2) then carries neither the in-workgroup
+// factorisation (a 5 x 5 Gauss-Jordan per lane group: the register-hungriest piece) nor its share of the kernel's spills.
+template <bool VD, int HYBRID = 0>
 __global__ void __launch_bounds__(WG_THREADS) radau_wg_kernel(RadauCtl* __restrict__ ctls, int64_t B, int64_t N, WgWork w, const DevConsts* __restrict__ consts,
                                                               double fd_threshold, P33 P, double E0, double E1, double E2, unsigned* __restrict__ next_instance,
-                                                              int hybrid = 0, int32_t* __restrict__ counts = nullptr, int32_t* __restrict__ lists = nullptr,
+                                                              int32_t* __restrict__ counts = nullptr, int32_t* __restrict__ lists = nullptr,
                                                               double* __restrict__ t_events = nullptr, const int32_t* __restrict__ run_list = nullptr,
                                                               int64_t todo = -1)
 {
+    constexpr int hybrid = HYBRID;
     __shared__ WgBuf buf;
     __shared__ double tabs[TABLE_DOUBLES];
     __shared__ RadauCtl sc;
@@ -241,7 +244,7 @@ __global__ void __launch_bounds__(WG_THREADS) radau_wg_kernel(RadauCtl* __restri
                 WG_TICK(2);
             }
             // ---- finite-difference Jacobian at (y, f): num_jac with its second trial step (fd_prepare / fd_columns / fd_finish kernels)
-            if (action & A_JAC) {
+            if (HYBRID != 1 && (action & A_JAC)) {
                 const double* f0 = wg_at(w.f, off);
                 double *fac = wg_at(w.fac, off), *h = wg_at(w.h, off), *yscale = wg_at(w.yscale, off), *YP = wg_at(w.YP, off), *FN = wg_at(w.FN, off);
                 double *Jraw = wg_at(w.Jraw, off), *maxdiff = wg_at(w.maxdiff, off), *scl = wg_at(w.scl, off), *hnew = wg_at(w.hnew, off), *J = wg_at(w.J, off);
@@ -322,7 +325,7 @@ __global__ void __launch_bounds__(WG_THREADS) radau_wg_kernel(RadauCtl* __restri
                 WG_TICK(3);
             }
             // ---- factorise mu_r I - J and mu_c I - J: block cyclic reduction, every level here (pcr_factor_kernel per level and system)
-            if (action & A_LU) {
+            if (HYBRID == 0 && (action & A_LU)) {
                 const double* J = wg_at(w.J, off);
                 const PcrSystem<double> Sr = wg_at(w.Sr, off);
                 const PcrSystem<cplx> Sc = wg_at(w.Sc, off);
