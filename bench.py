@@ -391,7 +391,7 @@ def main():
                         "valu_issue_frac = VALU wave-instructions of the launch (SQ_INSTS_VALU of the committed counter pass: a "
                         "property of code + input) / launch duration of THIS run / (1024 SIMDs x 2.4 GHz / 4 cycles)"}
         pmc = sqc = None
-        for tag in ("r03", "r02", "r01"):
+        for tag in ("r04", "r03", "r02", "r01"):
             f = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.json")
             if pmc is None and os.path.exists(f):
                 pmc = (tag, json.load(open(f)))

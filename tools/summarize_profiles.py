@@ -165,7 +165,7 @@ for wl in ("default", "default_no_reuse", "n65536", "rk45_single", "sweep_rk45",
                 acc[k]["dispatches"] = n
     out = {}
     for k, m in acc.items():
-        if "marl::" not in k or m.get("dispatches", 0) < 2 or not any(x in k for x in ("rk4_fused", "rk4_stream", "rk45_attempt", "sweep_kernel", "control", "reduce_chunks")):
+        if "marl" not in k or m.get("dispatches", 0) < 2 or not any(x in k for x in ("rk4_fused", "rk4_stream", "rk45_attempt", "sweep_kernel", "control", "reduce_chunks")):
             continue
         w = m.get("SQ_WAVES", 0)
         if w and "SQ_INSTS_VALU" in m:
