@@ -172,7 +172,7 @@ struct StencilBlock {
                     for (int f = 0; f < NF; f++) um[f] = ghost_lower(C->bc[f], ys[0][f]);
                 }
             }
-            point_rates<VD>(ys[0], um, up, K, T, pl, k[0], need_right_solids);
+            point_rates<VD, true, !CACHE>(ys[0], um, up, K, T, pl, k[0], need_right_solids);
             return;
         }
         double* e = lds + parity * (NSIDE * NF * BLK);
@@ -221,7 +221,7 @@ struct StencilBlock {
                     for (int f = 0; f < NF; f++) um[f] = ghost_lower(C->bc[f], ys[c][f]);
                 }
             }
-            point_rates<VD>(ys[c], um, up, K, T, pl[c], k[c], CPT == 1 ? need_right_solids : true);
+            point_rates<VD, true, !CACHE>(ys[c], um, up, K, T, pl[c], k[c], CPT == 1 ? need_right_solids : true);
         }
     }
 };

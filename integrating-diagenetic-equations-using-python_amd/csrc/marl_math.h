@@ -457,7 +457,7 @@ __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask
 #ifdef MARL_ABLATE_FV   // kernel-lab builds only: central gradients throughout
     fv_check = false;
 #endif
-    pl.fv_solutes = false;
+    pl.fv_solutes = MODE != TR_PLAIN;   // (cached modes: always the three-sigma form, see below)
     if (fv_check) {   // wave-uniform
         asm volatile("");   // a real branch (its five cheap operations would otherwise be speculated into every evaluation)
         const double Wd = W * den;
@@ -467,7 +467,11 @@ __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask
         // wave-uniform: does ANY lane need a weight for cCa / cCO3?  Their diffusion coefficients are ~200x the porosity's, so from
         // N ~ 100 cells on only the porosity's Peclet number reaches PECLET_MIN (every BASELINE size) - point_rates then evaluates one
         // sigma instead of three (a sigma of 0 gives the central gradient bit for bit, so nothing changes but the instruction count)
-        pl.fv_solutes = __builtin_amdgcn_ballot_w64(!(psol < PECLET_MIN)) != 0;
+        // Only without the transcendental cache (MODE == TR_PLAIN: the one-workgroup sweeps and the stand-alone RHS - the coarse grids,
+        // where the weights are live in every evaluation): the fused fine-grid kernels sit exactly at their 128-VGPR cap, and one more
+        // wave-uniform value carried across the exchange barrier tipped rk45_attempt_kernel into spilling inside its stage sequence
+        // (0 -> 28 B/lane of scratch, rk45_single -9 %) for a branch those kernels never take.
+        if constexpr (MODE == TR_PLAIN) pl.fv_solutes = __builtin_amdgcn_ballot_w64(!(psol < PECLET_MIN)) != 0;
         pl.Wd = Wd;
         if constexpr (MODE == TR_FILL || MODE == TR_AUTO) { if (!reuse) pc.fv_quiet = pmax < 0.9 * PECLET_MIN; }  // in range, Pe moves by < 1e-3 relative
     } else if constexpr (MODE == TR_FILL || MODE == TR_AUTO) {
@@ -495,7 +499,8 @@ __device__ __forceinline__ void point_local(const double (&uc)[NF], bool in_mask
 
 // uc/um/up: values at cell i, i-1, i+1 (ghosts already substituted).  r: the five rates (LHeureux_model.py:498-520).
 // mixed_upwind (wave-uniform): false promises pl.upw in every lane of the wave - up[0], up[1] are then not read.
-template <bool VD = false, bool SERIES = true>
+// SOLUTE_SKIP: honour pl.fv_solutes (callers without the transcendental cache); false: the three-sigma form, untouched since round 3
+template <bool VD = false, bool SERIES = true, bool SOLUTE_SKIP = false>
 __device__ __forceinline__ void point_rates(const double (&uc)[NF], const double (&um)[NF], const double (&up)[NF],
                                             const HotConsts& K, const Tables& T, const PointLocal& pl, double (&r)[NF], bool mixed_upwind = true)
 {
@@ -536,16 +541,23 @@ __device__ __forceinline__ void point_rates(const double (&uc)[NF], const double
     } else {
         const double W = pl.W, Wd = pl.Wd;
         const double pe_Phi = VD ? K.pe_Phi * (K.dPhi * rcp_nr(dPhi_cell())) : K.pe_Phi;   // delta_x / (2 dPhi)
-        const double s_p = fv_sigma<SERIES>(W * pe_Phi, W, T);
-        pg = ((1.0 - s_p) * p_f + (1.0 + s_p) * p_b) * K.hdx;
-        if (pl.fv_solutes) {   // wave-uniform (see point_local)
-            asm volatile("");
-            const double s_c = fv_sigma<SERIES>(Wd * K.pe_cCa, W, T), s_o = fv_sigma<SERIES>(Wd * K.pe_cCO3, W, T);
+        if constexpr (!SOLUTE_SKIP) {
+            const double s_c = fv_sigma<SERIES>(Wd * K.pe_cCa, W, T), s_o = fv_sigma<SERIES>(Wd * K.pe_cCO3, W, T), s_p = fv_sigma<SERIES>(W * pe_Phi, W, T);
             cg = ((1.0 - s_c) * c_f + (1.0 + s_c) * c_b) * K.hdx;
             og = ((1.0 - s_o) * o_f + (1.0 + s_o) * o_b) * K.hdx;
-        } else {               // both sigmas are 0 in every lane: ((1 - 0) c_f + (1 + 0) c_b) hdx, the same bits
-            cg = (c_f + c_b) * K.hdx;
-            og = (o_f + o_b) * K.hdx;
+            pg = ((1.0 - s_p) * p_f + (1.0 + s_p) * p_b) * K.hdx;
+        } else {
+            const double s_p = fv_sigma<SERIES>(W * pe_Phi, W, T);
+            pg = ((1.0 - s_p) * p_f + (1.0 + s_p) * p_b) * K.hdx;
+            if (pl.fv_solutes) {   // wave-uniform (see point_local)
+                asm volatile("");
+                const double s_c = fv_sigma<SERIES>(Wd * K.pe_cCa, W, T), s_o = fv_sigma<SERIES>(Wd * K.pe_cCO3, W, T);
+                cg = ((1.0 - s_c) * c_f + (1.0 + s_c) * c_b) * K.hdx;
+                og = ((1.0 - s_o) * o_f + (1.0 + s_o) * o_b) * K.hdx;
+            } else {               // both sigmas are 0 in every lane: ((1 - 0) c_f + (1 + 0) c_b) hdx, the same bits
+                cg = (c_f + c_b) * K.hdx;
+                og = (o_f + o_b) * K.hdx;
+            }
         }
     }
     const double h2 = pg * pl.h2f;                                      // common_helper2 (:472-473)
@@ -570,7 +582,7 @@ __device__ __forceinline__ void rhs_point(const double (&uc)[NF], const double (
 {
     PointLocal pl;
     point_local<MODE, STRIDE, VD, true>(uc, in_mask, K, C, T, pl, aux, pc, live);   // (LEGACY operation order: see point_local)
-    point_rates<VD, false>(uc, um, up, K, T, pl, r);
+    point_rates<VD, false, true>(uc, um, up, K, T, pl, r);
 }
 
 
