@@ -77,6 +77,15 @@ __device__ __forceinline__ double wave_from_right(double v)
     return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false));   // wave_shl:1
 }
 
+#ifdef MARL_LAB_PHASE_CLOCK   // kernel-lab build only (tools/rk4_lab.hip): shader-clock cycles per phase of an RHS evaluation, summed over every
+// evaluation of wave 0 of every workgroup: [0] edge writes, [1] own-cell phase (point_local), [2] wait at the exchange barrier, [3] neighbour
+// reads + boundary branch + stencil phase (point_rates), [4] between evaluations (RK combination, loads, stores), [5] evaluations counted
+__device__ unsigned long long marl_lab_phase[8];
+#define MARL_PHASE_MARK(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_acc[k] += t_ - ph_last; ph_last = t_; } while (0)
+#else
+#define MARL_PHASE_MARK(k) do { } while (0)
+#endif
+
 template <int BLK, int CPT, bool REUSE = true, bool VD = false>
 struct StencilBlock {
     static constexpr int WIN = BLK * CPT;
@@ -109,6 +118,14 @@ struct StencilBlock {
     __device__ __forceinline__ unsigned is_edge(int c) const { return (masks >> c) & 0x101u; }   // first or last: non-zero
     PointCache<(CACHE && CACHE_LDS) ? WIN : 0> cache[CACHE ? CPT : 1];  // centre of the transcendental expansions (TR_FILL / TR_REUSE / TR_AUTO)
     bool reuse_live[CPT] = {};   // wave-uniform, per cell: the centre is filled and no evaluation since has fallen out of range
+#ifdef MARL_LAB_PHASE_CLOCK
+    unsigned long long ph_acc[6] = {0, 0, 0, 0, 0, 0}, ph_last = __builtin_amdgcn_s_memtime();
+    __device__ __forceinline__ void phase_flush()
+    {
+        if (threadIdx.x == 0)
+            for (int k = 0; k < 6; k++) atomicAdd(&marl_lab_phase[k], ph_acc[k]);
+    }
+#endif
 
     // lds: LDS_DOUBLES doubles = edge exchange buffers followed by the log/exp tables (copied here; barrier inside).
     // g0: global index of this thread's first cell.
@@ -175,12 +192,14 @@ struct StencilBlock {
             point_rates<VD, true, !CACHE>(ys[0], um, up, K, T, pl, k[0], need_right_solids);
             return;
         }
+        MARL_PHASE_MARK(4);
         double* e = lds + parity * (NSIDE * NF * BLK);
 #pragma unroll
         for (int f = 0; f < NF; f++) {
             e[f * BLK + tid] = ys[0][f];
             if constexpr (CPT > 1) e[(NF + f) * BLK + tid] = ys[CPT - 1][f];
         }
+        MARL_PHASE_MARK(0);
         PointLocal pl[CPT];
 #pragma unroll
         for (int c = 0; c < CPT; c++) {
@@ -190,7 +209,9 @@ struct StencilBlock {
             if constexpr (CPT > 1) __builtin_amdgcn_sched_barrier(0);
 #endif
         }
+        MARL_PHASE_MARK(1);
         __syncthreads();
+        MARL_PHASE_MARK(2);
         const int tl = tid > 0 ? tid - 1 : 0;
         const int tr = tid < BLK - 1 ? tid + 1 : BLK - 1;
         double left[NF], right[NF];
@@ -223,6 +244,11 @@ struct StencilBlock {
             }
             point_rates<VD, true, !CACHE>(ys[c], um, up, K, T, pl[c], k[c], CPT == 1 ? need_right_solids : true);
         }
+#ifdef MARL_LAB_PHASE_CLOCK
+        asm volatile("" :: "v"(k[0][0]), "v"(k[0][4]));   // (the rates are complete before the mark)
+        MARL_PHASE_MARK(3);
+        ph_acc[5]++;
+#endif
     }
 };
 
@@ -560,6 +586,9 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(MARL_L
             for (int f = 0; f < NF; f++) yout[at<LAYOUT>(f, l, S.ld)] = y[c][f];
         }
     }
+#ifdef MARL_LAB_PHASE_CLOCK
+    sb.phase_flush();
+#endif
 #ifdef MARL_LAB_CLOCK
     if (threadIdx.x == 0 && blockIdx.x < 16384) {
         marl_lab_clock[3 * blockIdx.x] = __builtin_amdgcn_s_memtime() - lab_t0;

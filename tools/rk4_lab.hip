@@ -85,6 +85,20 @@ int main(int argc, char** argv)
                clk[nb / 2], clk[0], clk[nb - 1], life[nb / 2], life[0], life[nb - 1], (rmax - rmin) * 0.01);
     }
 #endif
+#ifdef MARL_LAB_PHASE_CLOCK
+    {
+        unsigned long long ph[8];
+        hipMemcpyFromSymbol(ph, HIP_SYMBOL(marl::marl_lab_phase), sizeof ph, 0, hipMemcpyDeviceToHost);
+        const double ev = (double)ph[5];
+        const char* name[5] = {"edge writes (5 ds_write)", "own-cell phase (point_local)", "wait at the exchange barrier", "neighbour reads + stencil phase (point_rates)",
+                               "between evaluations (RK combination, loads / stores)"};
+        double tot = 0;
+        for (int k = 0; k < 5; k++) tot += ph[k] / ev;
+        printf("shader-clock cycles per RHS evaluation of wave 0 of every workgroup (%.0f evaluations; six s_memtime marks per evaluation included):\n", ev);
+        for (int k = 0; k < 5; k++) printf("  %-58s %8.1f cycles  %5.1f %%\n", name[k], ph[k] / ev, 100.0 * ph[k] / ev / tot);
+        printf("  %-58s %8.1f cycles\n", "total per evaluation", tot);
+    }
+#endif
     const int done = (steps / LAB_NSTEPS) * LAB_NSTEPS;
     printf("BLK=%d CPT=%d NSTEPS=%d N=%lld: %.3f us/step, %.3e gp-steps/s (%.1f%% of 1e11), checksum %.15g\n", LAB_BLK, LAB_CPT, LAB_NSTEPS,
            (long long)N, best * 1e3 / done, (double)N * done / (best * 1e-3), (double)N * done / (best * 1e-3) / 1e9, chk);
