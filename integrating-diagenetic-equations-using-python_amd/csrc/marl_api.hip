@@ -583,22 +583,25 @@ static int default_rk4_variant(const marl_ctx* ctx)
     return n <= 98304 ? 4 : (n <= 262144 ? 3 : 2);
 }
 
+#ifndef MARL_LAB_STREAM_BLK   // (kernel-lab switch: threads per workgroup of the streamed loop; 512 = half the halo share, twice the waves per barrier)
+#define MARL_LAB_STREAM_BLK 256
+#endif
 // One dataflow launch for `levels` x `per` steps (rk4_stream_kernel): bufA -> ... -> (levels odd ? bufB : bufA)
 template <int NSTEPS, bool VD = false>
 static void launch_stream_t(marl_ctx* ctx, double* a, double* b, int layout, double dt, unsigned levels, unsigned tiles, unsigned blocks, double* c = nullptr)
 {
     if (layout == LAYOUT_TILED)
-        hipLaunchKernelGGL((rk4_stream_kernel<256, LAYOUT_TILED, NSTEPS, VD>), dim3(blocks), dim3(256), 0, ctx->stream, a, b, ctx->dconsts, ctx->slab, dt,
+        hipLaunchKernelGGL((rk4_stream_kernel<MARL_LAB_STREAM_BLK, LAYOUT_TILED, NSTEPS, VD>), dim3(blocks), dim3(MARL_LAB_STREAM_BLK), 0, ctx->stream, a, b, ctx->dconsts, ctx->slab, dt,
                            levels, tiles, ctx->sq, ctx->sq + 2, ctx->sq_sticky, ctx->sq_item_base, ctx->sq_level_base, c);
     else
-        hipLaunchKernelGGL((rk4_stream_kernel<256, LAYOUT_FIELD_MAJOR, NSTEPS, VD>), dim3(blocks), dim3(256), 0, ctx->stream, a, b, ctx->dconsts, ctx->slab,
+        hipLaunchKernelGGL((rk4_stream_kernel<MARL_LAB_STREAM_BLK, LAYOUT_FIELD_MAJOR, NSTEPS, VD>), dim3(blocks), dim3(MARL_LAB_STREAM_BLK), 0, ctx->stream, a, b, ctx->dconsts, ctx->slab,
                            dt, levels, tiles, ctx->sq, ctx->sq + 2, ctx->sq_sticky, ctx->sq_item_base, ctx->sq_level_base, c);
 }
 
 // *result: where the state is afterwards (a or b)
 static int rk4_stream(marl_ctx* ctx, double* a, double* b, int layout, double dt, int per, int64_t levels, double** result)
 {
-    const int64_t n = ctx->slab.out_hi - ctx->slab.out_lo, V = 256 - 8 * per, tiles = (n + V - 1) / V;
+    const int64_t n = ctx->slab.out_hi - ctx->slab.out_lo, V = MARL_LAB_STREAM_BLK - 8 * per, tiles = (n + V - 1) / V;
     if (!ctx->cus) {
         hipDeviceProp_t prop;
         HIP_OK(ctx, hipGetDeviceProperties(&prop, ctx->device));
@@ -628,7 +631,7 @@ static int rk4_stream(marl_ctx* ctx, double* a, double* b, int layout, double dt
         // (the item counter is 32 bits wide; an even number of levels per launch keeps the ping-pong orientation)
         const int64_t cap = (ctx->sq_max_items / tiles) & ~(int64_t)1;
         const int64_t lv = std::min<int64_t>(levels, std::max<int64_t>(cap, 2));
-        const unsigned blocks = (unsigned)std::min<int64_t>(lv * tiles, 4 * (int64_t)ctx->cus);   // 4 workgroups of 256 per CU are resident
+        const unsigned blocks = (unsigned)std::min<int64_t>(lv * tiles, (4 * 256 / MARL_LAB_STREAM_BLK) * (int64_t)ctx->cus);   // 4 workgroups of 256 per CU are resident
         // the LAST launch with an odd number (>= 3) of levels goes A -> B, B <-> C, ... -> A through a third buffer: the result lands where
         // the caller's state is and the whole-state copy afterwards goes away (12 us of a 20-step call at N = 2^20; option rk4_stream_third)
         double* c = nullptr;

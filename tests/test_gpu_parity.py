@@ -453,6 +453,28 @@ def test_rk45_event_root_on_a_large_grid_every_schedule(oracle, path):
     eq.close()
 
 
+@pytest.mark.parametrize("path", ["stream", "launches"])
+def test_rk45_large_grid_schedules_with_time_varying_porosity_diffusion(torch_cuda, oracle, path):
+    """The dPhi_variable instantiations of both schedules (rk45_stream_kernel<..., VD = true>, rk45_attempt_kernel<..., VD = true>) on a grid
+    that is not one workgroup, against the oracle's restatement of the variant (field-major layout, rejected attempts included)."""
+    torch = torch_cuda
+    N = 2500
+    p = scenario("A", N) | {"dPhi_variable": True}
+    eq = make_model(p)
+    eq.use_stream(torch.cuda.current_stream().cuda_stream)
+    set_rk45_path(eq, path)
+    y = synthetic_state(p, N, amplitude=0.05)
+    dx2 = (eq.Depths.length / N) ** 2
+    t1 = 40 * dx2
+    yref, st, *_ = oracle.rk45(oracle.params_from_model(eq), N, y, 0.0, t1, 0.5 * dx2, 1e-5, 1e-7)
+    yd = torch.from_numpy(y).cuda()
+    res = eq.integrate_rk45_device(yd.data_ptr(), (0.0, t1), 0.5 * dx2, 1e-5, 1e-7, 0)
+    torch.cuda.synchronize()
+    assert (res.status, res.n_accepted, res.n_rejected, res.nfev) == (st.status, st.n_accepted, st.n_rejected, st.nfev) and st.n_rejected > 0
+    assert rel_to_max(yd.cpu().numpy(), yref) <= RUN_TOL
+    eq.close()
+
+
 def test_rk45_persistent_loop_at_full_size_against_the_launch_per_attempt_loop(torch_cuda):
     """N = 2^20 (4 297 tiles on 1 024 resident workgroups: four static rounds + a remainder round handed out by the atomic counter):
     the persistent loop against one launch per attempt - same decisions, states equal to rounding (the two differ in the order of the
