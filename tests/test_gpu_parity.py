@@ -568,6 +568,24 @@ def test_nan_state_is_data_not_error(oracle):
     eq.close()
 
 
+@pytest.mark.parametrize("path", ["stream", "launches"])
+def test_nan_state_on_a_large_grid_rejects_down_to_the_minimum_step(oracle, path):
+    """The same invalid state (one cell with Phi < 0) on a grid that is not one workgroup, through both schedules of the adaptive loop:
+    every attempt's error norm is NaN - a NaN sum through the barrier's fixed-order addition / the record reduction, extrema that are never
+    read - so every attempt is rejected with factor 0.2 until the step falls below 10 ulp(t): status -1 after exactly the oracle's
+    number of rejections, nothing accepted."""
+    N = 3000
+    p = scenario("default", N)
+    eq = make_model(p)
+    set_rk45_path(eq, path)
+    y = synthetic_state(p, N)
+    y[4 * N + 1717] = -0.1
+    res = eq.integrate_rk45(y, (0.0, 1e-3), 1e-6, 1e-3, 1e-3, events=False)
+    _, st, *_ = oracle.rk45(oracle.params_from_model(eq), N, y, 0.0, 1e-3, 1e-6, 1e-3, 1e-3)
+    assert res.status == st.status == -1 and res.n_accepted == st.n_accepted == 0 and res.n_rejected == st.n_rejected > 10
+    eq.close()
+
+
 def test_full_size_rk4_against_oracle_and_layout_agreement(torch_cuda, oracle):
     """BASELINE headline size N = 2^20: a few fused steps against the oracle, and the two device layouts /
     two kernel variants against each other."""
