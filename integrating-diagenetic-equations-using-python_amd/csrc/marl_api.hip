@@ -830,8 +830,10 @@ static int rk45_stream_setup(marl_ctx* ctx)
 template <bool VD>
 static int launch_rk45_stream_t(marl_ctx* ctx, int layout, int64_t tiles, int64_t max_attempts, bool dd = false)
 {
-    auto kern = layout == LAYOUT_TILED ? rk45_stream_kernel<256, LAYOUT_TILED, VD> : rk45_stream_kernel<256, LAYOUT_FIELD_MAJOR, VD>;
-    int& occ = ctx->rs_occ[layout == LAYOUT_TILED ? 1 : 0][VD ? 1 : 0];
+    if (dd && layout != LAYOUT_FIELD_MAJOR) return fail(ctx, -1, "rk45 stream: slabs are field-major");
+    auto kern = dd ? rk45_stream_kernel<256, LAYOUT_FIELD_MAJOR, VD, true>
+                   : (layout == LAYOUT_TILED ? rk45_stream_kernel<256, LAYOUT_TILED, VD, false> : rk45_stream_kernel<256, LAYOUT_FIELD_MAJOR, VD, false>);
+    int& occ = ctx->rs_occ[layout == LAYOUT_TILED ? 1 : 0][VD ? 1 : 0];   // (the DD instantiation shares the field-major one's: same registers and LDS)
     if (!occ) {
         HIP_OK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, 0));
         if (occ < 1) return fail(ctx, -3, "rk45 stream: the kernel does not fit a compute unit");

@@ -1278,13 +1278,13 @@ __device__ unsigned long long marl_lab_clock45t[2048 * 8 * 8];   // tiles of att
 #ifndef MARL_STREAM_PARK   // fields of y parked in LDS (dp45_attempt): 4 leave LDS for exactly four workgroups per CU (40 448 of 40 960 bytes)
 #define MARL_STREAM_PARK 4
 #endif
-template <int BLK, int LAYOUT, bool VD = false>
+template <int BLK, int LAYOUT, bool VD = false, bool DD = false>
 __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8)))
 rk45_stream_kernel(double* Y0, double* Y1, double* F0, double* F1, const DevConsts* __restrict__ consts, Slab S, Rk45Ctrl* ctrl,
                    double* grec, Rk45Stream* sync, unsigned tiles, unsigned arrive_base, unsigned epoch_base, unsigned grab_base, unsigned max_attempts,
                    double* send = nullptr, int halo = 0)
 {
-    // send != NULL (one slab of a domain-decomposed grid; max_attempts = 1, all three bases 0): ONE attempt per launch, and the
+    // DD (one slab of a domain-decomposed grid; max_attempts = 1, all three bases 0; option dd_stream): ONE attempt per launch, and the
     // barrier's last workgroup, instead of deciding, writes the rank's message [record (8) | lower strip | upper strip] (what
     // reduce_chunks_kernel + slab_reduce_pack_kernel did) and re-arms the counters; the all-gather and slab_unpack_control_kernel
     // follow, and the next launch reads the common decision out of *ctrl.
@@ -1474,7 +1474,7 @@ rk45_stream_kernel(double* Y0, double* Y1, double* F0, double* F1, const DevCons
             if ((threadIdx.x & 63) == 0) s_wsum[threadIdx.x >> 6] = e2;
             MARL_STAMP45L(1);
             __syncthreads();
-            if (send) {   // (uniform) domain decomposition: the slab's record and strips into the rank's message; nothing is decided here
+            if constexpr (DD) {   // domain decomposition: the slab's record and strips into the rank's message; nothing is decided here
                 if (threadIdx.x == 0) {
                     double sumsq = 0.0;
 #pragma unroll
@@ -1534,7 +1534,7 @@ rk45_stream_kernel(double* Y0, double* Y1, double* F0, double* F1, const DevCons
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             MARL_STAMP45L(4);
         }
-        if (send) break;   // (one attempt per launch: nothing to wait for)
+        if constexpr (DD) break;   // (one attempt per launch: nothing to wait for)
         if (threadIdx.x == 0) {
             unsigned spins = 0;
             while (true) {

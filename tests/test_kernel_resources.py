@@ -67,7 +67,7 @@ def test_persistent_loops_keep_their_occupancy_and_bounded_scratch(recs):
     for name, r in pick(recs, "rk4_stream_kernelILi256E", "Lb0EEE").items():
         assert r["private_segment_fixed_size"] <= 36 and r["vgpr_count"] <= 128, (name, r)
     # persistent RK45: LDS must leave room for four workgroups per CU (4 x 40 960 = 160 KB), scratch only outside the six evaluations
-    for name, r in pick(recs, "rk45_stream_kernelILi256E", "Lb0EEE").items():
+    for name, r in pick(recs, "rk45_stream_kernelILi256E", "Lb0ELb0EEE").items():
         assert r["group_segment_fixed_size"] <= 40960 and r["vgpr_count"] <= 128 and r["private_segment_fixed_size"] <= 128, (name, r)
     # the 1024-thread adaptive sweep kernel: capped at 128 VGPRs by its shape; its scratch is on record (184 B), not allowed to grow
     for name, r in pick(recs, "rk45_sweep_kernelILi1024ELi1ELb0EEE").items():

@@ -60,3 +60,38 @@ def test_checker_dataflow_on_a_handwritten_listing():
     assert any(b.startswith("I1:") for b in bad)
     good = chk.check_function(chk.functions(listing(True), "rk4_stream_kernel")["k_rk4_stream_kernel_test"])
     assert not any(b.startswith("I1:") for b in good)
+
+
+@needs_toolchain
+def test_every_shipped_persistent_rk45_instantiation_keeps_its_invariants():
+    """rk45_stream_kernel: the decision record crosses XCDs without a fence, like the streamed RK4 tiles - J1-J5 of the checker."""
+    import check_stream_isa as chk
+    from marlpde_amd import _abi
+    res = chk.check_rk45_text(chk.disassemble_so(_abi.LIB_PATH))
+    # both layouts x constant / time-varying porosity diffusion + the one-attempt-per-launch (DD) pair on field-major slabs
+    assert len(res) == 6 and sum("Lb1EEEv" in n for n in res) == 2, sorted(res)
+    assert {n: bad for n, bad in res.items() if bad} == {}
+
+
+def test_rk45_checker_flags_a_record_published_before_the_stores_are_acknowledged():
+    import check_stream_isa as chk
+
+    def listing(wait, sc1=True):
+        rows = [("global_load_dwordx2", "v[0:1], v2, s[0:1]"),                      # prologue: plain is fine
+                ("s_barrier", ""),                                                   # loop head (address base + 4)
+                ("global_load_dwordx2", "v[0:1], v2, s[0:1] sc1" if sc1 else "v[0:1], v2, s[0:1]"),
+                ("global_store_dwordx2", "v2, v[0:1], s[0:1] sc1"),
+                ("global_atomic_min_f64", "v2, v[0:1], s[2:3] sc1")]
+        if wait:
+            rows.append(("s_waitcnt", "vmcnt(0)"))
+        rows += [("global_atomic_add", "v3, v2, v4, s[4:5] sc0 sc1"), ("s_waitcnt", "vmcnt(0)" if wait else "lgkmcnt(0)"), ("s_barrier", ""),
+                 ("global_store_dwordx4", "v2, v[4:7], s[6:7] sc1"), ("global_atomic_add", "v3, v2, v4, s[8:9] sc0 sc1"),
+                 ("s_cbranch_scc1", "x"), ("s_endpgm", "")]
+        text = ["0000000000001000 <k_rk45_stream_kernel_test>:"]
+        for i, (op, args) in enumerate(rows):
+            tgt = " <k_rk45_stream_kernel_test+0x4>" if op.startswith("s_cbranch") else ""
+            text.append(f"\t{op} {args}    // {0x1000 + 4 * i:012X}: 00000000{tgt}")
+        return chk.functions("\n".join(text), "rk45_stream_kernel")["k_rk45_stream_kernel_test"]
+    assert chk.check_rk45_function(listing(True)) == []
+    assert any(b.startswith("J3:") for b in chk.check_rk45_function(listing(False)))
+    assert any(b.startswith("J2:") for b in chk.check_rk45_function(listing(True, sc1=False)))

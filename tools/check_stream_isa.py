@@ -32,6 +32,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEFAULT_SO = os.path.join(ROOT, "integrating-diagenetic-equations-using-python_amd", "csrc", "libmarl_hip.so")
 EXPECTED_BARRIERS = 9
+PUBLISH_STORES = 1   # rk45_stream_kernel: one global_store_dwordx4 site (a loop over the replicas of the record)
 
 
 def disassemble_so(so_path):
@@ -159,9 +160,98 @@ def check_function(ins):
     return bad
 
 
+def check_rk45_function(ins, dd=False):
+    """Invariants of rk45_stream_kernel (the persistent Dormand-Prince loop; csrc/marl_kernels.h), on the same data-flow:
+      J1  no LDS operation outstanding at any s_barrier (the decision, the grabbed tile index, the 'last workgroup' word travel through LDS);
+      J2  every 64-bit / 128-bit global load or store inside a loop (state, per-workgroup sums, monitors, the 16-byte record) carries
+          sc1; plain ones only in the prologue, outside every loop (constants and the controller as the host or the previous launch
+          left them: a kernel boundary makes those visible).  The one-attempt-per-launch instantiation (DD) also stores its message
+          plainly - the launch's end publishes it - and has no record;
+      J3  the decision record (global_store_dwordx4 ... sc1) is stored only where every state store / extremum atomic of this workgroup
+          has been acknowledged (s_waitcnt vmcnt(0)) and then followed by an s_barrier (its ticket lies in between);
+      J4  at least one publish store (none in DD), one ticket / grab atomic add each, extremum atomics present (global_atomic_min_f64);
+      J5  no indirect control flow."""
+    bad = []
+    back_edges = [(tgt, a) for a, op, _args, tgt in ins if tgt is not None and tgt <= a]
+    in_loop = lambda a: any(lo <= a <= hi for lo, hi in back_edges)  # noqa: E731
+    index = {a: i for i, (a, *_rest) in enumerate(ins)}
+    n = len(ins)
+    succ = [[] for _ in range(n)]
+    for i, (a, op, args, tgt) in enumerate(ins):
+        if op in ("s_setpc_b64", "s_swappc_b64", "s_call_b64"):
+            bad.append(f"J5: indirect control flow ({op}) at {a:#x}")
+        if op == "s_endpgm":
+            continue
+        if op == "s_branch":
+            succ[i].append(index[tgt])
+            continue
+        if op.startswith("s_cbranch"):
+            succ[i].append(index[tgt])
+        if i + 1 < n:
+            succ[i].append(i + 1)
+    L, V, B = 1, 2, 4
+    state_in = [None] * n
+    state_in[0] = 0
+    work = [0]
+    while work:
+        i = work.pop()
+        s = state_in[i]
+        a, op, args, _ = ins[i]
+        if op.startswith("ds_"):
+            s |= L
+        elif op == "global_store_dwordx2" or op == "global_atomic_min_f64":
+            s |= V | B
+        elif op == "s_waitcnt":
+            if "lgkmcnt(0)" in args:
+                s &= ~L
+            if "vmcnt(0)" in args:
+                s &= ~V
+        elif op == "s_barrier":
+            if not s & V:
+                s &= ~B
+        for j in succ[i]:
+            merged = s if state_in[j] is None else (state_in[j] | s)
+            if merged != state_in[j]:
+                state_in[j] = merged
+                work.append(j)
+    publish = adds = mins = 0
+    for i, (a, op, args, _) in enumerate(ins):
+        s = state_in[i]
+        if s is None:
+            continue
+        if op == "s_barrier" and s & L:
+            bad.append(f"J1: s_barrier at {a:#x} can be reached with an LDS operation outstanding")
+        elif op in ("global_load_dwordx2", "global_store_dwordx2", "global_load_dwordx4", "global_store_dwordx4") and "sc1" not in args:
+            if op.startswith("global_load") and not in_loop(a):
+                pass
+            elif op == "global_store_dwordx2" and dd:
+                pass
+            else:
+                bad.append(f"J2: {op} at {a:#x} without sc1")
+        if op == "global_store_dwordx4":
+            publish += 1
+            if s & V:
+                bad.append(f"J3: decision record stored at {a:#x} with state stores / extremum atomics possibly unacknowledged")
+            elif s & B:
+                bad.append(f"J3: decision record stored at {a:#x} without an s_barrier after the acknowledgement of the workgroup's stores")
+        elif op == "global_atomic_add":
+            adds += 1
+        elif op == "global_atomic_min_f64":
+            mins += 1
+    if publish != (0 if dd else PUBLISH_STORES) or adds < 2 or mins < 1:
+        bad.append(f"J4: {publish} publish stores, {adds} atomic adds (ticket, tile grab), {mins} fp64 atomic minima")
+    return bad
+
+
 def check_text(text, pattern="rk4_stream_kernel"):
     fs = functions(text, pattern)
     return {name: check_function(ins) for name, ins in fs.items()}
+
+
+def check_rk45_text(text):
+    """name -> violations for every rk45_stream_kernel instantiation (the last template argument, Lb1E before the parameter list, is DD)."""
+    fs = functions(text, "rk45_stream_kernel")
+    return {name: check_rk45_function(ins, dd="Lb1EEEv" in name) for name, ins in fs.items()}
 
 
 def main():
@@ -171,6 +261,7 @@ def main():
     if not res:
         print("no rk4_stream_kernel instantiation found")
         return 2
+    res.update(check_rk45_text(text))
     rc = 0
     for name, bad in res.items():
         print(("FAIL " if bad else "ok   ") + name)
