@@ -59,7 +59,7 @@ struct marl_ctx {
     double* rs_grec = nullptr;
     unsigned* rs_host = nullptr;   // pinned: copy of {arrive, sticky}
     unsigned rs_arrive_base = 0, rs_epoch_base = 0, rs_grab_base = 0, rs_G = 0, rs_grabs_per_attempt = 0;
-    int rs_occ[2][2] = {{0, 0}, {0, 0}};   // resident workgroups per CU of the instantiation [tiled][VD]
+    int rs_occ[3][2] = {{0, 0}, {0, 0}, {0, 0}};   // resident workgroups per CU of the instantiation [field-major / tiled / one attempt per launch][VD]
     int64_t rk45_stream = 1;       // the adaptive loop of one grid as ONE launch per batch of attempts (rk45_stream_kernel): 0 never, 1 where it is faster (grids of up to kRk45StreamRounds rounds of resident workgroups), 2 always
     int64_t dd_stream = 0;         // domain-decomposed loop inside the library: 0 (default) attempt + reduce + pack launches; 1 / 2: the slab's attempt as ONE launch of the persistent kernel whose last workgroup packs the rank's message (1: slabs of up to kRk45StreamRounds rounds, 2: always) - built for the 8-GPU shard size and measured there NOT faster (44.5 us against 34.9 + 4.7 + 4.7 us, profiles/r04_lab_rk45_stream.log)
     int64_t rk45_stream_attempts = 4096;   // attempts per launch at most (the host looks at the status and the sticky flag in between)
@@ -833,7 +833,7 @@ static int launch_rk45_stream_t(marl_ctx* ctx, int layout, int64_t tiles, int64_
     if (dd && layout != LAYOUT_FIELD_MAJOR) return fail(ctx, -1, "rk45 stream: slabs are field-major");
     auto kern = dd ? rk45_stream_kernel<256, LAYOUT_FIELD_MAJOR, VD, true>
                    : (layout == LAYOUT_TILED ? rk45_stream_kernel<256, LAYOUT_TILED, VD, false> : rk45_stream_kernel<256, LAYOUT_FIELD_MAJOR, VD, false>);
-    int& occ = ctx->rs_occ[layout == LAYOUT_TILED ? 1 : 0][VD ? 1 : 0];   // (the DD instantiation shares the field-major one's: same registers and LDS)
+    int& occ = ctx->rs_occ[dd ? 2 : (layout == LAYOUT_TILED ? 1 : 0)][VD ? 1 : 0];   // (per instantiation: the resident-grid bound below rests on it)
     if (!occ) {
         HIP_OK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, 0));
         if (occ < 1) return fail(ctx, -3, "rk45 stream: the kernel does not fit a compute unit");
