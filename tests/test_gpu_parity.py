@@ -475,12 +475,16 @@ def test_rk45_large_grid_schedules_with_time_varying_porosity_diffusion(torch_cu
     eq.close()
 
 
-def test_rk45_persistent_loop_at_full_size_against_the_launch_per_attempt_loop(torch_cuda):
+# (a tile of the attempt kernel advances 244 cells; an MI355X holds 4 x 256 = 1 024 resident workgroups of the persistent kernel)
+@pytest.mark.parametrize("N", [1 << 20, 244 * 1024, 244 * 1024 + 1, 244 * 2048, 244 * 1024 + 244 * 1023],
+                         ids=["4297-tiles", "1024-tiles-no-remainder", "1025-tiles-remainder-of-one", "2048-tiles-no-remainder", "2047-tiles"])
+def test_rk45_persistent_loop_at_full_size_against_the_launch_per_attempt_loop(torch_cuda, N):
     """N = 2^20 (4 297 tiles on 1 024 resident workgroups: four static rounds + a remainder round handed out by the atomic counter):
     the persistent loop against one launch per attempt - same decisions, states equal to rounding (the two differ in the order of the
-    error sum and in the controller's pow); the persistent loop twice - bit-identical, whoever computed the remainder tiles."""
+    error sum and in the controller's pow); the persistent loop twice - bit-identical, whoever computed the remainder tiles.  The other
+    sizes are the edges of the remainder logic: whole rounds only (no remainder counter in play), a remainder of ONE tile, one tile short of
+    two whole rounds."""
     torch = torch_cuda
-    N = 1 << 20
     p = scenario("default", N)
     y = synthetic_state(p, N, amplitude=0.01)
     dx2 = ((p["max_depth"] / p["Xstar"]) / N) ** 2
