@@ -1566,15 +1566,25 @@ int marl_slab_run(marl_ctx* ctx, marl_stats* stats)
     if (int rc = ensure_part(ctx, (size_t)std::max<int64_t>(nb + kReduceGroups, 1024))) return rc;
     const int msg = dd_msg(ctx);
     int64_t executed = 0;
-    if (ctx->dd_world == 1 && !ctx->rccl_comm && rk45_use_stream(ctx, v)) {
-        // ONE slab and no communicator: nothing is exchanged - the single-grid integrator's persistent loop (same kernel, same bits)
+    if (ctx->dd_world == 1 && !ctx->rccl_comm) {
+        // ONE slab and no communicator: nothing is exchanged - the single-grid integrator's loop (same kernels, same bits): the persistent
+        // launch up to ~750 000 cells, attempt + reduction + control launches above (one launch less per attempt than packing a message
+        // nobody reads and unpacking it again)
+        const bool streamed = rk45_use_stream(ctx, v);
         while (true) {
-            if (int rc = launch_rk45_stream(ctx, v, LAYOUT_FIELD_MAJOR, ctx->rk45_stream_attempts)) return rc;
+            if (streamed) {
+                if (int rc = launch_rk45_stream(ctx, v, LAYOUT_FIELD_MAJOR, ctx->rk45_stream_attempts)) return rc;
+            } else {
+                const int64_t batch = attempts_per_batch(ctx->poll, ctx->dd_max_attempts, executed);
+                for (int64_t i = 0; i < batch; i++)
+                    if (int rc = launch_attempt(ctx, v, LAYOUT_FIELD_MAJOR)) return rc;
+            }
             HIP_OK(ctx, hipMemcpyAsync(ctx->hctrl, ctx->dctrl, sizeof(Rk45Ctrl), hipMemcpyDeviceToHost, ctx->stream));
             HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
             const int64_t before = executed;
             executed = ctx->hctrl->attempts - (ctx->hctrl->status == ST_RUNNING ? 1 : 0);
-            if (int rc = rk45_stream_account(ctx, executed - before)) return rc;
+            if (streamed)
+                if (int rc = rk45_stream_account(ctx, executed - before)) return rc;
             if (ctx->hctrl->status != ST_RUNNING) break;
         }
         ctrl_to_stats(*ctx->hctrl, stats);
